@@ -1,0 +1,98 @@
+"""ctypes binding of libflacarray_hip.so (C ABI: include/flacarray_hip.h).
+
+There is no CPU fallback: if the library cannot be loaded, or no HIP device is visible when a
+compute entry point is called, the call fails loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libflacarray_hip.so")
+
+# every symbol include/flacarray_hip.h declares
+SYMBOLS = [
+    "encode_i32",
+    "encode_i32_threaded",
+    "decode_i32",
+    "float32_to_int32",
+    "int32_to_float32",
+    "fa_encode_workspace_bytes",
+    "fa_encode_i32_device_begin",
+    "fa_encode_i32_device_finish",
+    "fa_decode_i32_device",
+    "fa_decode_slices_i32_device",
+    "fa_float32_to_int32_device",
+    "fa_int32_to_float32_device",
+    "fa_release_scratch",
+    "fa_device_count",
+    "fa_version",
+]
+
+# error bits (flacarray.h:20-40 + this library's additions)
+ERROR_DEVICE = 1 << 24
+ERROR_NAN_INPUT = 1 << 25
+
+_lib = None
+_libc = None
+
+
+def lib():
+    """Load (once) and return the shared library, with argument types declared."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m flacarray_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback."
+        )
+    L = ctypes.CDLL(LIB_PATH)
+    i64, u32, vp, cint = ctypes.c_int64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int
+    pi64 = ctypes.POINTER(ctypes.c_int64)
+    L.encode_i32.argtypes = [vp, i64, i64, u32, pi64, vp, ctypes.POINTER(vp)]
+    L.encode_i32.restype = cint
+    L.encode_i32_threaded.argtypes = L.encode_i32.argtypes
+    L.encode_i32_threaded.restype = cint
+    L.decode_i32.argtypes = [vp, vp, vp, i64, i64, i64, i64, vp, ctypes.c_bool]
+    L.decode_i32.restype = cint
+    L.float32_to_int32.argtypes = [vp, i64, i64, vp, vp, vp, vp]
+    L.float32_to_int32.restype = cint
+    L.int32_to_float32.argtypes = [vp, i64, i64, vp, vp, vp]
+    L.int32_to_float32.restype = None
+    L.fa_encode_workspace_bytes.argtypes = [i64, i64, u32]
+    L.fa_encode_workspace_bytes.restype = i64
+    L.fa_encode_i32_device_begin.argtypes = [vp, i64, i64, u32, vp, i64, vp, vp, pi64, vp, vp]
+    L.fa_encode_i32_device_begin.restype = cint
+    L.fa_encode_i32_device_finish.argtypes = [i64, i64, u32, vp, vp, vp, vp]
+    L.fa_encode_i32_device_finish.restype = cint
+    L.fa_decode_i32_device.argtypes = [vp, i64, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, vp]
+    L.fa_decode_i32_device.restype = cint
+    L.fa_decode_slices_i32_device.argtypes = [vp, i64, vp, vp, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.fa_decode_slices_i32_device.restype = cint
+    L.fa_float32_to_int32_device.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp]
+    L.fa_float32_to_int32_device.restype = cint
+    L.fa_int32_to_float32_device.argtypes = [vp, i64, i64, vp, vp, vp, vp]
+    L.fa_int32_to_float32_device.restype = cint
+    L.fa_release_scratch.argtypes = []
+    L.fa_release_scratch.restype = None
+    L.fa_device_count.argtypes = []
+    L.fa_device_count.restype = cint
+    L.fa_version.argtypes = []
+    L.fa_version.restype = ctypes.c_char_p
+    _lib = L
+    return L
+
+
+def libc_free(addr):
+    global _libc
+    if _libc is None:
+        _libc = ctypes.CDLL(None)
+        _libc.free.argtypes = [ctypes.c_void_p]
+        _libc.free.restype = None
+    _libc.free(addr)
+
+
+def require_device():
+    """Raise unless a HIP device is visible (the product path never falls back to the CPU)."""
+    if lib().fa_device_count() <= 0:
+        raise RuntimeError("flacarray_amd: no HIP device visible; the MI355X path has no CPU fallback")

@@ -1,0 +1,374 @@
+"""FlacArray container (reference: src/flacarray/array.py:19-884).
+
+Holds the concatenated per-stream FLAC bytes plus the int64 `stream_starts` / `stream_nbytes`
+index (and float32 offsets/gains for quantised float data) and decompresses numpy-style
+selections on the fly through the MI355X decode path.  Same constructor arguments,
+properties, `from_array` / `to_array` / `__getitem__` / `__eq__` semantics as the reference;
+HDF5/Zarr I/O and the mpi4py distribution are outside this hot path (multi-GPU sharding lives
+in flacarray_amd.dist).  `read_slices` is an addition: one batched launch for many scattered
+(stream, sample-range) requests, which the reference can only serve one call at a time.
+"""
+import copy
+
+import numpy as np
+
+from .compress import array_compress
+from .decompress import array_decompress_slice
+from .utils import log
+
+
+class FlacArray:
+    """FLAC compressed array representation; the last axis is the compressed one.
+
+    Constructed directly only to copy (`FlacArray(other)`); use `from_array` otherwise.
+    """
+
+    def __init__(
+        self,
+        other,
+        shape=None,
+        global_shape=None,
+        compressed=None,
+        dtype=None,
+        stream_starts=None,
+        stream_nbytes=None,
+        stream_offsets=None,
+        stream_gains=None,
+        mpi_comm=None,
+        mpi_dist=None,
+    ):
+        if other is not None:
+            self._shape = copy.deepcopy(other._shape)
+            self._global_shape = copy.deepcopy(other._global_shape)
+            self._compressed = copy.deepcopy(other._compressed)
+            self._dtype = np.dtype(other._dtype)
+            self._stream_starts = copy.deepcopy(other._stream_starts)
+            self._stream_nbytes = copy.deepcopy(other._stream_nbytes)
+            self._stream_offsets = copy.deepcopy(other._stream_offsets)
+            self._stream_gains = copy.deepcopy(other._stream_gains)
+            self._mpi_dist = copy.deepcopy(other._mpi_dist)
+            self._mpi_comm = other._mpi_comm
+        else:
+            self._shape = tuple(shape)
+            self._global_shape = tuple(global_shape) if global_shape is not None else tuple(shape)
+            self._compressed = compressed
+            self._dtype = np.dtype(dtype)
+            self._stream_starts = stream_starts
+            self._stream_nbytes = stream_nbytes
+            self._stream_offsets = stream_offsets
+            self._stream_gains = stream_gains
+            self._mpi_comm = mpi_comm
+            self._mpi_dist = mpi_dist
+        if self._mpi_comm is not None:
+            raise NotImplementedError("mpi4py communicators are not supported; see flacarray_amd.dist for multi-GPU sharding")
+        self._init_params()
+
+    def _init_params(self):
+        # a 1-D original keeps its flattened shape; internally there is always a stream axis
+        if len(self._shape) == 1:
+            self._flatten_single = True
+            self._local_shape = (1, self._shape[0])
+        else:
+            self._flatten_single = False
+            self._local_shape = self._shape
+        self._local_nbytes = self._compressed.nbytes
+        self._global_nbytes = self._local_nbytes
+        self._global_proc_nbytes = [self._local_nbytes]
+        self._global_stream_starts = self._stream_starts
+        self._global_stream_nbytes = self._stream_nbytes
+        self._leading_shape = self._local_shape[:-1]
+        self._global_leading_shape = self._global_shape[:-1]
+        self._stream_size = self._local_shape[-1]
+        self._local_nstreams = int(np.prod(self._leading_shape))
+        self._global_nstreams = int(np.prod(self._global_leading_shape)) if len(self._global_leading_shape) else 1
+        self._typestr = self._dtype_str(self._dtype)
+        self._is_int64 = self._dtype == np.dtype(np.int64) or self._dtype == np.dtype(np.float64)
+
+    @staticmethod
+    def _dtype_str(dt):
+        for name in ("float64", "float32", "int64", "int32"):
+            if dt == np.dtype(name):
+                return name
+        raise RuntimeError(f"Unsupported dtype '{dt}'")
+
+    # ---- shapes of the decompressed array ----
+    @property
+    def shape(self):
+        """The shape of the local, uncompressed array."""
+        return self._shape
+
+    @property
+    def global_shape(self):
+        return self._global_shape
+
+    @property
+    def leading_shape(self):
+        """The local shape of leading uncompressed dimensions."""
+        return self._leading_shape
+
+    @property
+    def global_leading_shape(self):
+        return self._global_leading_shape
+
+    @property
+    def stream_size(self):
+        """The uncompressed length of each stream."""
+        return self._stream_size
+
+    # ---- properties of the compressed data ----
+    @property
+    def nbytes(self):
+        """Bytes used by the compressed data."""
+        return self._local_nbytes
+
+    @property
+    def global_nbytes(self):
+        return self._global_nbytes
+
+    @property
+    def global_process_nbytes(self):
+        return self._global_proc_nbytes
+
+    @property
+    def nstreams(self):
+        return self._local_nstreams
+
+    @property
+    def global_nstreams(self):
+        return self._global_nstreams
+
+    @property
+    def compressed(self):
+        """The concatenated raw bytes of all streams."""
+        return self._compressed
+
+    @property
+    def stream_starts(self):
+        return self._stream_starts
+
+    @property
+    def stream_nbytes(self):
+        return self._stream_nbytes
+
+    @property
+    def global_stream_starts(self):
+        return self._global_stream_starts
+
+    @property
+    def global_stream_nbytes(self):
+        return self._global_stream_nbytes
+
+    @property
+    def stream_offsets(self):
+        """The value subtracted from each stream during conversion to int32."""
+        return self._stream_offsets
+
+    @property
+    def stream_gains(self):
+        """The gain factor for each stream during conversion to int32."""
+        return self._stream_gains
+
+    @property
+    def mpi_comm(self):
+        return self._mpi_comm
+
+    @property
+    def mpi_dist(self):
+        return self._mpi_dist
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    @property
+    def typestr(self):
+        return self._typestr
+
+    # ---- numpy-style selection -> decode ----
+    @staticmethod
+    def _slice_nelem(slc, dim):
+        start, stop, step = slc.indices(dim)
+        return max((stop - start) // step, 0)
+
+    def _get_full_key(self, key):
+        """Pad the user key to one entry per dimension of the local shape (array.py:297-337)."""
+        ndim = len(self._local_shape)
+        if self._flatten_single:
+            if isinstance(key, tuple):
+                if len(key) != 1:
+                    raise ValueError(f"Slice key {key} is not valid for single, flattened stream.")
+                full_key = [0, key[0]]
+            else:
+                full_key = [0, key]
+        else:
+            full_key = list(key) if isinstance(key, tuple) else [key]
+        if len(full_key) > ndim:
+            raise ValueError(f"Invalid slice key {key}, too many dimensions")
+        full_key.extend([slice(None)] * (ndim - len(full_key)))
+        return full_key
+
+    def _get_leading_axes(self, full_key):
+        """Output leading shape and bool keep-mask for the leading axes (array.py:339-378)."""
+        if self._flatten_single:
+            keep = np.zeros(self._leading_shape, dtype=bool)
+            keep[0] = True
+            return (), keep
+        leading_shape = []
+        keep_slice = []
+        for axis, axkey in enumerate(full_key[:-1]):
+            if isinstance(axkey, (int, np.integer)):
+                if axkey < 0 or axkey >= self._local_shape[axis]:
+                    leading_shape.append(0)  # out of range: a zero-length result
+            else:
+                leading_shape.append(self._slice_nelem(axkey, self._local_shape[axis]))
+            keep_slice.append(axkey)
+        if len(keep_slice) == 0:
+            return tuple(leading_shape), None
+        if len(keep_slice) != len(self._leading_shape):
+            raise ValueError(f"keep_view {keep_slice} does not match leading dimensions {len(self._leading_shape)}")
+        keep = np.zeros(self._leading_shape, dtype=bool)
+        if 0 not in leading_shape:
+            keep[tuple(keep_slice)] = True
+        return tuple(leading_shape), keep
+
+    def _get_sample_axis(self, full_key):
+        """(first, last, sample_shape) of the stream-axis selection (array.py:380-407)."""
+        sample_key = full_key[-1]
+        if sample_key is None:
+            return (0, self._stream_size, (self._stream_size,))
+        if isinstance(sample_key, slice):
+            start, stop, step = sample_key.indices(self._stream_size)
+            if step != 1:
+                raise ValueError("Only stride==1 supported on stream slices")
+            if stop - start <= 0:
+                return (0, 0, (0,))
+            return (start, stop, (stop - start,))
+        if isinstance(sample_key, (int, np.integer)):
+            return (sample_key, sample_key + 1, ())
+        raise ValueError("Stream dimension supports contiguous slices or single indices.")
+
+    def __getitem__(self, raw_key):
+        """Decompress a selection on the fly; result shape equals numpy's for the same key."""
+        key = self._get_full_key(raw_key)
+        leading_shape, keep = self._get_leading_axes(key)
+        first, last, sample_shape = self._get_sample_axis(key)
+        full_shape = leading_shape + sample_shape
+        n_total = 0 if len(full_shape) == 0 else int(np.prod(full_shape))
+        if len(full_shape) == 0 and not (0 in leading_shape):
+            n_total = 1  # a single element: every axis indexed by an integer
+        if n_total == 0:
+            return np.zeros(full_shape, dtype=self._dtype)
+        arr, _ = array_decompress_slice(
+            self._compressed,
+            self._stream_size,
+            self._stream_starts,
+            self._stream_nbytes,
+            stream_offsets=self._stream_offsets,
+            stream_gains=self._stream_gains,
+            keep=keep,
+            first_stream_sample=first,
+            last_stream_sample=last,
+            is_int64=self._is_int64,
+        )
+        return arr.reshape(full_shape)
+
+    def __delitem__(self, key):
+        raise RuntimeError("Cannot delete individual streams")
+
+    def __setitem__(self, key, value):
+        raise RuntimeError("Cannot modify individual byte streams")
+
+    def __repr__(self):
+        return f"<FlacArray {self._typestr} shape={self._shape} bytes={self._local_nbytes}>"
+
+    def __eq__(self, other):
+        if self._shape != other._shape or self._dtype != other._dtype or self._global_shape != other._global_shape:
+            log.debug("FlacArray shape/dtype mismatch")
+            return False
+        if not np.array_equal(self._stream_starts, other._stream_starts):
+            return False
+        if not np.array_equal(self._compressed, other._compressed):
+            return False
+        for mine, theirs in ((self._stream_offsets, other._stream_offsets), (self._stream_gains, other._stream_gains)):
+            if (mine is None) != (theirs is None):
+                return False
+            if mine is not None and not np.allclose(mine, theirs):
+                return False
+        return True
+
+    def to_array(self, keep=None, stream_slice=None, keep_indices=False, use_threads=False):
+        """Decompress into a numpy array (array.py:518-584).
+
+        `stream_slice`: step-1 slice of samples taken from every stream (normalised with
+        slice.indices(); the reference forwards raw start/stop, so negative values there decode
+        the whole stream).  `keep`: bool mask over the leading shape; the result is then the
+        2-D array of kept streams (and their indices if `keep_indices`).
+        """
+        first_samp = None
+        last_samp = None
+        if stream_slice is not None:
+            if stream_slice.step is not None and stream_slice.step != 1:
+                raise RuntimeError("Only stream slices with a step size of 1 are supported")
+            first_samp, last_samp, _ = stream_slice.indices(self._stream_size)
+        arr, indices = array_decompress_slice(
+            self._compressed,
+            self._stream_size,
+            self._stream_starts,
+            self._stream_nbytes,
+            stream_offsets=self._stream_offsets,
+            stream_gains=self._stream_gains,
+            keep=keep,
+            first_stream_sample=first_samp,
+            last_stream_sample=last_samp,
+            is_int64=self._is_int64,
+            use_threads=use_threads,
+            no_flatten=(not self._flatten_single),
+        )
+        if keep is not None and keep_indices:
+            return (arr, indices)
+        return arr
+
+    def read_slices(self, streams, first, count):
+        """Batched random access (addition to the reference API).
+
+        streams: flat (C-order) stream indices; first/count: sample ranges.  Returns a list of
+        1-D arrays, one per request, decoded with ONE kernel launch on the GPU.
+        """
+        import torch
+
+        from .libflacarray import decode_slices_device
+
+        dev = torch.device("cuda", torch.cuda.current_device())
+        comp = torch.from_numpy(np.ascontiguousarray(self._compressed)).to(dev)
+        st = torch.from_numpy(np.ascontiguousarray(self._stream_starts).reshape(-1)).to(dev)
+        nb = torch.from_numpy(np.ascontiguousarray(self._stream_nbytes).reshape(-1)).to(dev)
+        off = gain = None
+        if self._stream_offsets is not None:
+            off = torch.from_numpy(np.ascontiguousarray(self._stream_offsets).reshape(-1))
+            gain = torch.from_numpy(np.ascontiguousarray(self._stream_gains).reshape(-1))
+        out, out_off = decode_slices_device(comp, st, nb, self._stream_size, streams, first, count, offsets=off, gains=gain)
+        flat = out.cpu().numpy()
+        count = np.asarray(count, dtype=np.int64)
+        return [flat[o : o + c] for o, c in zip(out_off, count)]
+
+    @classmethod
+    def from_array(cls, arr, level=5, quanta=None, precision=None, mpi_comm=None, use_threads=False):
+        """Construct a FlacArray from a numpy ndarray (array.py:587-637)."""
+        if mpi_comm is not None:
+            raise NotImplementedError("mpi4py communicators are not supported; see flacarray_amd.dist")
+        compressed, starts, nbytes, offsets, gains = array_compress(
+            arr, level=level, quanta=quanta, precision=precision, use_threads=use_threads
+        )
+        return FlacArray(
+            None,
+            shape=arr.shape,
+            global_shape=arr.shape,
+            compressed=compressed,
+            dtype=arr.dtype,
+            stream_starts=starts,
+            stream_nbytes=nbytes,
+            stream_offsets=offsets,
+            stream_gains=gains,
+            mpi_comm=None,
+            mpi_dist=None,
+        )

@@ -1,0 +1,45 @@
+"""Build the HIP extension in-tree: flacarray_amd/lib/libflacarray_hip.so (gfx950).
+
+hipcc cross-compiles without a GPU; the built .so travels with the repo snapshot.
+"""
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(_HERE, "csrc", "flacarray_hip.hip")
+OUT = os.path.join(_HERE, "lib", "libflacarray_hip.so")
+DEPS = [
+    SRC,
+    os.path.join(_HERE, "csrc", "flac_math.hpp"),
+    os.path.join(_HERE, "csrc", "encode_kernels.hpp"),
+    os.path.join(_HERE, "csrc", "decode_kernels.hpp"),
+    os.path.join(_HERE, "csrc", "quantize_kernels.hpp"),
+    os.path.join(os.path.dirname(_HERE), "include", "flacarray_hip.h"),
+]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared"]
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(d) > t for d in DEPS)
+
+
+def build(force=False, verbose=False):
+    """Compile the library if it is missing or older than its sources; returns its path."""
+    if not force and not needs_build():
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + ["-o", OUT + ".tmp", SRC]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    os.replace(OUT + ".tmp", OUT)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,574 @@
+// decode_kernels.hpp -- HIP kernels of the FLAC decode path for gfx950 (wave64).
+//
+// Replaces what the reference reaches through libFLAC in decode()
+// (src/flacarray/libflacarray/decompress.c:194-313): stream/metadata parsing, frame location
+// (libFLAC's seek_absolute binary search, decompress.c:283), Rice/escape decoding, predictor
+// restoration, slice trimming (dec_write_callback, decompress.c:66-101) and the optional
+// int32 -> float32 restore (int32_to_float32, utils.c:350-368) fused into the store.
+//
+//   K6  parse_streams_kernel      one thread per stream: metadata blocks, STREAMINFO, SEEKTABLE
+//       build_frame_table_kernel  frame byte offsets from the SEEKTABLE (one thread per frame)
+//       walk_frames_kernel        streams without a complete SEEKTABLE (e.g. written by libFLAC
+//                                 through the reference): one thread walks the stream's frames
+//   K7  decode_frames_kernel      one LANE per frame (Rice decoding and LPC restoration are
+//                                 serial recurrences inside a frame; frames are independent),
+//                                 64 frames per wavefront, samples transposed through LDS so
+//                                 that HBM stores are 128-byte row segments
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "flac_math.hpp"
+
+namespace fa {
+
+constexpr int kErrDecodeInit = 1 << 13;     // flacarray.h:33 ERROR_DECODE_INIT
+constexpr int kErrDecodeProcess = 1 << 14;  // flacarray.h:34 ERROR_DECODE_PROCESS
+constexpr int kErrDecodeSeek = 1 << 18;     // flacarray.h:38 ERROR_DECODE_SEEK
+
+struct StreamMeta {
+    int64_t first_frame;  // absolute byte offset of the first frame in the blob
+    int64_t seek_abs;     // absolute byte offset of the first seek point, or -1
+    int64_t end_abs;      // absolute end of the stream's bytes
+    int32_t npoints;
+    int32_t B;    // fixed blocksize from STREAMINFO
+    int32_t bps;  // bits per sample from STREAMINFO
+    int32_t flags;  // 1 = complete seek table
+};
+
+__device__ __forceinline__ uint64_t load_be64(const uint8_t* p) {
+    uint64_t v = 0;
+    for (int i = 0; i < 8; ++i) v = (v << 8) | p[i];
+    return v;
+}
+
+__global__ __launch_bounds__(256) void parse_streams_kernel(const uint8_t* __restrict__ blob, const int64_t* __restrict__ starts,
+                                                            const int64_t* __restrict__ nbytes, int64_t n_stream,
+                                                            int64_t stream_size, StreamMeta* __restrict__ meta,
+                                                            int* __restrict__ err) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_stream) return;
+    const uint8_t* p = blob + starts[s];
+    const int64_t nb = nbytes[s];
+    StreamMeta m;
+    m.first_frame = -1; m.seek_abs = -1; m.end_abs = starts[s] + nb; m.npoints = 0; m.B = 0; m.bps = 0; m.flags = 0;
+    bool ok = nb >= 42 && p[0] == 'f' && p[1] == 'L' && p[2] == 'a' && p[3] == 'C';
+    int64_t off = 4;
+    while (ok) {
+        if (off + 4 > nb) { ok = false; break; }
+        const int last = p[off] >> 7, type = p[off] & 0x7f;
+        const int64_t len = ((int64_t)p[off + 1] << 16) | ((int64_t)p[off + 2] << 8) | p[off + 3];
+        off += 4;
+        if (off + len > nb) { ok = false; break; }
+        if (type == 0 && len >= 34) {
+            const int minb = (p[off] << 8) | p[off + 1], maxb = (p[off + 2] << 8) | p[off + 3];
+            m.B = maxb;
+            if (minb != maxb) ok = false;  // variable-blocksize streams are never produced on this path
+            m.bps = (((p[off + 12] & 1) << 4) | (p[off + 13] >> 4)) + 1;
+        } else if (type == 3) {
+            m.seek_abs = starts[s] + off;
+            m.npoints = (int32_t)(len / 18);
+        }
+        off += len;
+        if (last) break;
+    }
+    if (ok && m.B > 0) {
+        m.first_frame = starts[s] + off;
+        const int64_t nf = (stream_size + m.B - 1) / m.B;
+        if (m.seek_abs >= 0 && m.npoints == nf) m.flags = 1;
+    } else {
+        atomicOr(err, kErrDecodeInit);
+    }
+    meta[s] = m;
+}
+
+__global__ __launch_bounds__(256) void build_frame_table_kernel(const uint8_t* __restrict__ blob, const StreamMeta* __restrict__ meta,
+                                                                int64_t n_stream, int64_t nf, int32_t B, int64_t* __restrict__ ftab,
+                                                                int* __restrict__ err) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_stream * nf) return;
+    const int64_t s = t / nf, f = t - s * nf;
+    const StreamMeta m = meta[s];
+    if (m.first_frame < 0) return;
+    if (m.B != B) { atomicOr(err, kErrDecodeInit); return; }
+    if (!(m.flags & 1)) return;
+    const uint8_t* sp = blob + m.seek_abs + 18 * f;
+    const uint64_t sn = load_be64(sp), off = load_be64(sp + 8);
+    if (sn != (uint64_t)f * (uint64_t)B) { atomicOr(err, kErrDecodeSeek); ftab[t] = -1; return; }
+    ftab[t] = m.first_frame + (int64_t)off;
+}
+
+// ------------------------------------------------------------------------------------------
+// Per-lane MSB-first bit reader over global memory with a 16-byte register prefetch queue
+// ------------------------------------------------------------------------------------------
+struct BitReader {
+    const uint8_t* base;  // readable range [base, lim)
+    const uint8_t* lim;
+    const uint8_t* wp;    // next 16-byte chunk (16-byte aligned address, may be outside the range)
+    uint4 cur, nxt;
+    int idx;              // next dword of cur
+    uint64_t win;         // next bits, MSB first
+    int nbits;            // valid bits in win
+    int64_t used;         // bits consumed since init
+
+    __device__ __forceinline__ uint4 load16(const uint8_t* q) const {
+        if (q >= base && q + 16 <= lim) return *reinterpret_cast<const uint4*>(q);
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 16; ++i)
+            if (q + i >= base && q + i < lim) w[i >> 2] |= (uint32_t)q[i] << (8 * (i & 3));
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __device__ __forceinline__ uint32_t next_dword() {
+        uint32_t w = (idx == 0) ? cur.x : (idx == 1) ? cur.y : (idx == 2) ? cur.z : cur.w;
+        idx++;
+        if (idx == 4) {
+            cur = nxt;
+            nxt = load16(wp);
+            wp += 16;
+            idx = 0;
+        }
+        return __builtin_bswap32(w);
+    }
+    __device__ __forceinline__ void refill() {
+        if (nbits <= 32) {
+            win |= (uint64_t)next_dword() << (32 - nbits);
+            nbits += 32;
+        }
+    }
+    __device__ __forceinline__ void init(const uint8_t* b, const uint8_t* l, const uint8_t* start) {
+        base = b; lim = l;
+        const uintptr_t a = reinterpret_cast<uintptr_t>(start);
+        const uint8_t* q = reinterpret_cast<const uint8_t*>(a & ~(uintptr_t)15);
+        cur = load16(q);
+        nxt = load16(q + 16);
+        wp = q + 32;
+        idx = (int)((a >> 2) & 3);
+        win = 0; nbits = 0; used = 0;
+        refill();
+        const int drop = (int)(a & 3) * 8;
+        win <<= drop;
+        nbits -= drop;
+        refill();
+    }
+    // n in 1..32
+    __device__ __forceinline__ uint32_t get(int n) {
+        const uint32_t v = (uint32_t)(win >> (64 - n));
+        win <<= n;
+        nbits -= n;
+        used += n;
+        refill();
+        return v;
+    }
+    __device__ __forceinline__ int32_t get_signed(int n) {
+        if (n == 0) return 0;
+        const uint32_t v = get(n);
+        return (int32_t)(v << (32 - n)) >> (32 - n);
+    }
+    // number of 0 bits before the next 1 bit; consumes the 1
+    __device__ __forceinline__ uint32_t unary() {
+        uint32_t q = 0;
+        for (;;) {
+            const uint32_t hi = (uint32_t)(win >> 32);
+            if (hi) {
+                const int z = __clz((int)hi);
+                win <<= (z + 1);
+                nbits -= (z + 1);
+                used += (z + 1);
+                refill();
+                return q + (uint32_t)z;
+            }
+            q += 32;
+            win <<= 32;
+            nbits -= 32;
+            used += 32;
+            refill();
+            if (q > (1u << 24)) return q;  // corrupt stream guard: every wave reaches an exit
+        }
+    }
+    __device__ __forceinline__ void skip(int64_t n) {
+        while (n > 0) {
+            const int c = n > 32 ? 32 : (int)n;
+            win <<= c; nbits -= c; used += c; n -= c;
+            refill();
+        }
+    }
+};
+
+struct FrameHeader {
+    int bs;
+    int bps;
+    int ok;
+};
+
+// frame header (RFC 9639 9.1); CRC-8 verified
+__device__ __forceinline__ FrameHeader read_frame_header(BitReader& br, int si_bps) {
+    FrameHeader h;
+    h.ok = 0; h.bs = 0; h.bps = 0;
+    uint8_t c8 = 0;
+    const uint32_t b01 = br.get(16);
+    c8 = crc8_byte(c8, (uint8_t)(b01 >> 8));
+    c8 = crc8_byte(c8, (uint8_t)b01);
+    if ((b01 & 0xFFFE) != 0xFFF8) return h;
+    if (b01 & 1) return h;  // variable blocksize
+    const uint32_t b2 = br.get(8), b3 = br.get(8);
+    c8 = crc8_byte(c8, (uint8_t)b2);
+    c8 = crc8_byte(c8, (uint8_t)b3);
+    const int bsc = (int)(b2 >> 4), src = (int)(b2 & 15), ch = (int)(b3 >> 4), ssc = (int)((b3 >> 1) & 7);
+    if (ch != 0 || (b3 & 1)) return h;
+    const uint32_t u0 = br.get(8);
+    c8 = crc8_byte(c8, (uint8_t)u0);
+    int extra = 0;
+    if (u0 & 0x80) {
+        int mbit = 0x40;
+        while ((u0 & mbit) && extra < 7) { extra++; mbit >>= 1; }
+        if (extra == 0 || extra > 6) return h;
+    }
+    for (int i = 0; i < extra; ++i) c8 = crc8_byte(c8, (uint8_t)br.get(8));
+    int bs;
+    if (bsc == 0) return h;
+    else if (bsc == 1) bs = 192;
+    else if (bsc <= 5) bs = 576 << (bsc - 2);
+    else if (bsc == 6) { const uint32_t v = br.get(8); c8 = crc8_byte(c8, (uint8_t)v); bs = (int)v + 1; }
+    else if (bsc == 7) { const uint32_t v = br.get(16); c8 = crc8_byte(c8, (uint8_t)(v >> 8)); c8 = crc8_byte(c8, (uint8_t)v); bs = (int)v + 1; }
+    else bs = 256 << (bsc - 8);
+    if (src == 12) { c8 = crc8_byte(c8, (uint8_t)br.get(8)); }
+    else if (src == 13 || src == 14) { const uint32_t v = br.get(16); c8 = crc8_byte(c8, (uint8_t)(v >> 8)); c8 = crc8_byte(c8, (uint8_t)v); }
+    else if (src == 15) return h;
+    const uint32_t got = br.get(8);
+    if (got != c8) return h;
+    int bps;
+    switch (ssc) {
+        case 0: bps = si_bps; break;
+        case 1: bps = 8; break;
+        case 2: bps = 12; break;
+        case 4: bps = 16; break;
+        case 5: bps = 20; break;
+        case 6: bps = 24; break;
+        case 7: bps = 32; break;
+        default: return h;
+    }
+    h.bs = bs; h.bps = bps; h.ok = 1;
+    return h;
+}
+
+// Walk every frame of streams that carry no complete seek table.  One thread per stream; the
+// walk parses but does not reconstruct (no prediction).
+__global__ __launch_bounds__(64) void walk_frames_kernel(const uint8_t* __restrict__ blob, int64_t blob_bytes,
+                                                         const StreamMeta* __restrict__ meta, int64_t n_stream, int64_t nf,
+                                                         int32_t B, int64_t stream_size, int64_t* __restrict__ ftab,
+                                                         int* __restrict__ err) {
+    const int64_t s = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (s >= n_stream) return;
+    const StreamMeta m = meta[s];
+    if (m.first_frame < 0 || (m.flags & 1) || m.B != B) return;
+    int64_t at = m.first_frame;
+    for (int64_t f = 0; f < nf; ++f) {
+        ftab[s * nf + f] = at;
+        if (at >= m.end_abs) { atomicOr(err, kErrDecodeProcess); for (int64_t r = f; r < nf; ++r) ftab[s * nf + r] = -1; return; }
+        BitReader br;
+        br.init(blob, blob + blob_bytes, blob + at);
+        FrameHeader h = read_frame_header(br, m.bps);
+        bool ok = h.ok;
+        if (ok) {
+            const uint32_t sf = br.get(8);
+            int tc = (int)((sf >> 1) & 0x3f);
+            int wasted = 0;
+            if (sf & 0x80) ok = false;
+            if (sf & 1) wasted = (int)br.unary() + 1;
+            const int bps = h.bps - wasted;
+            int order = 0;
+            bool pred = false;
+            if (bps <= 0) ok = false;
+            else if (tc == 0) br.skip(bps);
+            else if (tc == 1) br.skip((int64_t)bps * h.bs);
+            else if (tc >= 8 && tc <= 12) { order = tc - 8; pred = true; br.skip((int64_t)bps * order); }
+            else if (tc >= 32) {
+                order = (tc & 31) + 1; pred = true;
+                br.skip((int64_t)bps * order);
+                const int prec = (int)br.get(4) + 1;
+                br.get(5);
+                br.skip((int64_t)prec * order);
+            } else ok = false;
+            if (ok && pred) {
+                const int method = (int)br.get(2);
+                const int po = (int)br.get(4);
+                const int plen = method ? 5 : 4, esc = method ? 31 : 15;
+                if (method > 1 || order > h.bs) ok = false;
+                const int ps = h.bs >> po;
+                for (int p = 0; ok && p < (1 << po); ++p) {
+                    const int n = (p == 0) ? ps - order : ps;
+                    if (n < 0) { ok = false; break; }
+                    const int k = (int)br.get(plen);
+                    if (k == esc) {
+                        const int nbw = (int)br.get(5);
+                        br.skip((int64_t)nbw * n);
+                    } else {
+                        for (int j = 0; j < n; ++j) {
+                            const uint32_t q = br.unary();
+                            if (q > (1u << 24)) { ok = false; break; }
+                            if (k) br.get(k);
+                        }
+                    }
+                }
+            }
+        }
+        if (!ok) { atomicOr(err, kErrDecodeProcess); for (int64_t r = f + 1; r < nf; ++r) ftab[s * nf + r] = -1; return; }
+        const int64_t bits = (br.used + 7) & ~(int64_t)7;
+        at += (bits >> 3) + 2;
+    }
+    (void)stream_size;
+}
+
+// ------------------------------------------------------------------------------------------
+// K7: decode.  One lane per task = (output row, frame).  Two task layouts:
+//   grid mode  : task t -> stream t / nfr, frame f0 + t % nfr, one [first,last) range for all
+//   list mode  : explicit arrays (scattered slices)
+// ------------------------------------------------------------------------------------------
+struct DecodeArgs {
+    const uint8_t* blob;
+    int64_t blob_bytes;
+    const StreamMeta* meta;
+    const int64_t* ftab;  // [n_stream][nf] absolute frame offsets
+    int64_t nf;           // frames per stream
+    int32_t B;
+    int64_t stream_size;
+    int64_t n_tasks;
+    // grid mode
+    int64_t nfr;       // frames per row in the requested range
+    int64_t f0;        // first frame of the range
+    int64_t first;     // first decoded sample
+    int64_t n_decode;  // samples per output row
+    // list mode (task_stream != null)
+    const int64_t* task_stream;
+    const int64_t* task_frame;
+    const int64_t* task_first;    // slice first sample (stream coordinates)
+    const int64_t* task_last;     // slice end (exclusive)
+    const int64_t* task_out_off;  // output element offset of the slice's first sample
+    // outputs
+    int32_t* out_i32;
+    float* out_f32;         // when non-null: dequantised output instead of out_i32
+    const float* offsets;   // per stream
+    const float* gains;
+    int* err;
+};
+
+constexpr int kTileSamples = 32;
+constexpr int kTileStride = 36;  // words per lane row in the LDS transpose tile
+constexpr int kFlagNeed12 = 1, kFlagNeed32 = 2;
+
+// MO = history depth of this variant (8, 12 or 32).  Tasks whose predictor order exceeds MO
+// are left for a later pass (flag word); tasks with order <= MO_DONE were done by an earlier one.
+template <int MO, int MO_DONE>
+__device__ __forceinline__ void decode_wave(const DecodeArgs& a, int32_t* tile, int64_t* row_out, int2* row_rng, float2* row_fg,
+                                            int lane, int64_t task, bool has_task, int* flags) {
+    // ---- per-lane task setup ----
+    int64_t s = 0, f = 0, sl_first = 0, sl_last = 0, out_off = 0;
+    if (has_task) {
+        if (a.task_stream) {
+            s = a.task_stream[task]; f = a.task_frame[task];
+            sl_first = a.task_first[task]; sl_last = a.task_last[task];
+            out_off = a.task_out_off[task];
+        } else {
+            s = task / a.nfr; f = a.f0 + (task - s * a.nfr);
+            sl_first = a.first; sl_last = a.first + a.n_decode;
+            out_off = s * a.n_decode;
+        }
+    }
+    const int64_t fstart = f * (int64_t)a.B;
+    int lo = 0, hi = 0;  // valid sample range inside this frame
+    int bs = 0;
+    BitReader br;
+    int mode = 3;  // 0 const, 1 verbatim, 2 predictive, 3 idle
+    int order = 0, bps = 0, wasted = 0;
+    int32_t cval = 0;
+    double scale = 1.0;
+    double c[MO], h[MO];
+#pragma unroll
+    for (int j = 0; j < MO; ++j) { c[j] = 0.0; h[j] = 0.0; }
+    int plen = 4, esc = 15, ps = 0, pleft = 0, k = 0, escw = -1;
+
+    if (has_task) {
+        bool bad = false;
+        bool is_lpc = false;
+        const StreamMeta m = a.meta[s];
+        const int64_t at = a.ftab[s * a.nf + f];
+        if (m.first_frame < 0 || at < 0) bad = true;
+        else {
+            br.init(a.blob, a.blob + a.blob_bytes, a.blob + at);
+            const FrameHeader fh = read_frame_header(br, m.bps);
+            int64_t expect = a.stream_size - fstart;
+            if (expect > a.B) expect = a.B;
+            if (!fh.ok || fh.bs != (int)expect) bad = true;
+            else {
+                bs = fh.bs;
+                const uint32_t sf = br.get(8);
+                const int tc = (int)((sf >> 1) & 0x3f);
+                if (sf & 0x80) bad = true;
+                if (sf & 1) wasted = (int)br.unary() + 1;
+                bps = fh.bps - wasted;
+                if (bps <= 0 || bps > 32) bad = true;
+                else if (tc == 0) { mode = 0; cval = br.get_signed(bps); }
+                else if (tc == 1) { mode = 1; }
+                else if (tc >= 8 && tc <= 12) { mode = 2; order = tc - 8; }
+                else if (tc >= 32) { mode = 2; order = (tc & 31) + 1; is_lpc = true; }
+                else bad = true;
+                if (order > bs) bad = true;
+            }
+        }
+        if (!bad) {
+            if (order > MO) {  // a later pass with a deeper history decodes this frame
+                atomicOr(flags, order > 12 ? kFlagNeed32 : kFlagNeed12);
+                mode = 3;
+            } else if (order <= MO_DONE) {
+                mode = 3;  // decoded by an earlier pass
+            }
+        }
+        if (!bad && mode == 2) {
+            // ---- warm-up samples, predictor description, residual header (serial per lane) ----
+            for (int i = 0; i < order; ++i) {
+                const int32_t x = br.get_signed(bps);
+                tile[lane * kTileStride + i] = (int32_t)((uint32_t)x << wasted);
+#pragma unroll
+                for (int jj = 0; jj < MO; ++jj)
+                    if (jj == (i % MO)) h[jj] = (double)x;
+            }
+            if (is_lpc) {
+                const int prec = (int)br.get(4) + 1;
+                const int sh = br.get_signed(5);
+                if (prec == 16 || sh < 0) bad = true;
+                for (int j = 0; j < order; ++j) {
+                    const double v = (double)br.get_signed(prec);
+#pragma unroll
+                    for (int jj = 0; jj < MO; ++jj)
+                        if (jj == j) c[jj] = v;
+                }
+                scale = bitsd((uint64_t)(1023 - (sh < 0 ? 0 : sh)) << 52);
+            } else {
+                if (order == 1) { c[0] = 1.0; }
+                else if (order == 2) { c[0] = 2.0; c[1] = -1.0; }
+                else if (order == 3) { c[0] = 3.0; c[1] = -3.0; c[2] = 1.0; }
+                else if (order == 4) { c[0] = 4.0; c[1] = -6.0; c[2] = 4.0; c[3] = -1.0; }
+            }
+            const int method = (int)br.get(2);
+            const int po = (int)br.get(4);
+            plen = method ? 5 : 4;
+            esc = method ? 31 : 15;
+            ps = bs >> po;
+            if (method > 1 || (po > 0 && (ps << po) != bs) || ps < order) bad = true;
+            pleft = -order;  // partition 0 is short by `order`
+        }
+        if (bad) { mode = 3; atomicOr(a.err, kErrDecodeProcess); }
+        if (mode != 3) {
+            int64_t l = sl_first - fstart, h2 = sl_last - fstart;
+            if (l < 0) l = 0;
+            if (h2 > bs) h2 = bs;
+            lo = (int)l;
+            hi = (int)(h2 > l ? h2 : l);
+        }
+    }
+    // row descriptors for the cooperative store
+    row_out[lane] = out_off + (fstart - sl_first);  // output element index of frame sample 0
+    row_rng[lane] = make_int2(lo, hi);
+    if (a.out_f32) {
+        float og = 0.0f, cf = 1.0f;
+        if (mode != 3) {
+            og = a.offsets[s];
+            cf = (float)(1.0 / (double)a.gains[s]);  // utils.c:361
+        }
+        row_fg[lane] = make_float2(og, cf);
+    }
+    const bool out_aligned = ((reinterpret_cast<uintptr_t>(a.out_f32 ? (const void*)a.out_f32 : (const void*)a.out_i32) & 15) == 0);
+
+    const int bs_max = a.B;  // uniform loop bound (B >= every frame's blocksize)
+    for (int i0 = 0; i0 < bs_max; i0 += MO) {
+#pragma unroll
+        for (int u = 0; u < MO; ++u) {
+            const int i = i0 + u;
+            if (i < bs) {
+                if (mode == 2) {
+                    if (i >= order) {
+                        if (pleft <= 0) {
+                            k = (int)br.get(plen);
+                            escw = -1;
+                            if (k == esc) escw = (int)br.get(5);
+                            pleft += ps;
+                        }
+                        int32_t r;
+                        if (escw >= 0) r = br.get_signed(escw);
+                        else {
+                            const uint32_t q = br.unary();
+                            const uint32_t uu = (q << k) | (k ? br.get(k) : 0u);
+                            r = (int32_t)(uu >> 1) ^ -(int32_t)(uu & 1);
+                        }
+                        pleft--;
+                        double sum = 0.0;
+#pragma unroll
+                        for (int j = 0; j < MO; ++j) sum = __builtin_fma(c[j], h[(u + MO - 1 - j) % MO], sum);
+                        const double xd = (double)r + fa_floor(sum * scale);
+                        h[u] = xd;
+                        tile[lane * kTileStride + (i & (kTileSamples - 1))] = (int32_t)((uint32_t)(int32_t)xd << wasted);
+                    }
+                } else if (mode == 1) {
+                    const int32_t x = br.get_signed(bps);
+                    tile[lane * kTileStride + (i & (kTileSamples - 1))] = (int32_t)((uint32_t)x << wasted);
+                } else if (mode == 0) {
+                    tile[lane * kTileStride + (i & (kTileSamples - 1))] = (int32_t)((uint32_t)cval << wasted);
+                }
+            }
+            if ((i & (kTileSamples - 1)) == kTileSamples - 1) {
+                // cooperative store of the tile: 8 rows x 32 samples per pass, 16 bytes per lane
+                __builtin_amdgcn_wave_barrier();
+                const int tbase = i & ~(kTileSamples - 1);
+#pragma unroll 2
+                for (int it = 0; it < 8; ++it) {
+                    const int r = it * 8 + (lane >> 3);
+                    const int cb = 4 * (lane & 7);
+                    const int4 v = *reinterpret_cast<const int4*>(&tile[r * kTileStride + cb]);
+                    const int2 rg = row_rng[r];
+                    const int si = tbase + cb;
+                    if (si + 3 >= rg.x && si < rg.y) {
+                        const int64_t ob = row_out[r] + si;
+                        const bool full = (si >= rg.x) && (si + 3 < rg.y) && out_aligned && ((ob & 3) == 0);
+                        if (a.out_f32) {
+                            const float2 fg = row_fg[r];
+                            float4 o;
+                            o.x = __fadd_rn(fg.x, __fmul_rn(fg.y, (float)v.x));  // utils.c:364
+                            o.y = __fadd_rn(fg.x, __fmul_rn(fg.y, (float)v.y));
+                            o.z = __fadd_rn(fg.x, __fmul_rn(fg.y, (float)v.z));
+                            o.w = __fadd_rn(fg.x, __fmul_rn(fg.y, (float)v.w));
+                            if (full) *reinterpret_cast<float4*>(a.out_f32 + ob) = o;
+                            else {
+                                if (si + 0 >= rg.x && si + 0 < rg.y) a.out_f32[ob + 0] = o.x;
+                                if (si + 1 >= rg.x && si + 1 < rg.y) a.out_f32[ob + 1] = o.y;
+                                if (si + 2 >= rg.x && si + 2 < rg.y) a.out_f32[ob + 2] = o.z;
+                                if (si + 3 >= rg.x && si + 3 < rg.y) a.out_f32[ob + 3] = o.w;
+                            }
+                        } else {
+                            if (full) *reinterpret_cast<int4*>(a.out_i32 + ob) = v;
+                            else {
+                                if (si + 0 >= rg.x && si + 0 < rg.y) a.out_i32[ob + 0] = v.x;
+                                if (si + 1 >= rg.x && si + 1 < rg.y) a.out_i32[ob + 1] = v.y;
+                                if (si + 2 >= rg.x && si + 2 < rg.y) a.out_i32[ob + 2] = v.z;
+                                if (si + 3 >= rg.x && si + 3 < rg.y) a.out_i32[ob + 3] = v.w;
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+
+template <int MO, int MO_DONE>
+__global__ __launch_bounds__(256) void decode_frames_kernel(DecodeArgs a, int* flags) {
+    __shared__ __attribute__((aligned(16))) int32_t tiles[4][64 * kTileStride];
+    __shared__ int64_t row_out[4][64];
+    __shared__ int2 row_rng[4][64];
+    __shared__ float2 row_fg[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t task = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    decode_wave<MO, MO_DONE>(a, tiles[wave], row_out[wave], row_rng[wave], row_fg[wave], lane, task, task < a.n_tasks, flags);
+}
+
+}  // namespace fa

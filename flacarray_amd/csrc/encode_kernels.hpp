@@ -1,0 +1,878 @@
+// encode_kernels.hpp -- HIP kernels of the FLAC encode path for gfx950 (wave64).
+//
+// Replaces what the reference reaches through libFLAC in encode()/encode_threaded()
+// (src/flacarray/libflacarray/compress.c:133-270, 274-435): per-frame predictor search,
+// residual, Rice partitioning and the bitstream writer, plus the concatenation of the
+// per-stream buffers (compress.c:402-429).
+//
+//   K3  encode_frames_kernel   one wavefront per frame (<= 4096 samples staged in LDS):
+//                              analysis + bit packing into a per-frame scratch slot
+//   K4  stream_scan_kernel /   frame sizes -> per-frame offsets, per-stream nbytes, starts
+//       starts_scan_kernel
+//   K5  write_headers_kernel   "fLaC" + STREAMINFO + SEEKTABLE of every stream
+//       compact_frames_kernel  slot -> final blob (byte-shifted copy) + CRC-16 of each frame
+//
+// LDS image of one frame (20304 B, 8 waves per CU):
+//   smp   65 chunks x 68 words   chunk c holds samples [64(c-1), 64c); 4 pad words per chunk make
+//                                the lane-per-chunk ds_read_b128 conflict free; chunk 0 is zeros
+//   ring  512 words              analysis scratch, then the circular bit buffer of the writer
+//   psum  64 x u64, kpar 64 B    Rice partition sums / chosen parameters
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "flac_math.hpp"
+
+namespace fa {
+
+struct FrameInfo {  // optional per-frame decision record (parity debugging)
+    int32_t type, order, porder, wasted, shift, precision, nbytes, blocksize;
+};
+
+struct EncodeArgs {
+    const int32_t* data;  // [n_stream][stream_size]
+    int64_t n_stream;
+    int64_t stream_size;
+    int64_t nframes;  // frames per stream
+    int32_t B;        // nominal blocksize
+    int32_t tail_bs;  // samples in the last frame of a stream
+    int32_t max_lpc_order;
+    int32_t max_porder;
+    int32_t precision;
+    const float* win;       // [B]
+    const float* win_tail;  // [tail_bs]
+    uint8_t* slots;         // [n_stream*nframes][kSlotBytes]
+    uint32_t* frame_bytes;  // [n_stream*nframes]
+    FrameInfo* info;        // [n_stream*nframes] or null
+};
+
+constexpr int kChunkStride = 68;
+constexpr int kSmpWords = 65 * kChunkStride;  // 4420
+constexpr int kRingWords = 512;
+constexpr int kRingMask = kRingWords - 1;
+constexpr int kLdsWords = kSmpWords + kRingWords + 128 + 16;  // 5076 words = 20304 B
+
+__device__ __forceinline__ int smp_idx(int s) { return kChunkStride * ((s >> 6) + 1) + (s & 63); }
+
+// ---- wave-level helpers (64 lanes) -------------------------------------------------------
+__device__ __forceinline__ double wave_sum_butterfly(double v) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) v = v + __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        double o = __shfl_xor(v, off, 64);
+        v = (o > v) ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) v += (uint64_t)__shfl_xor((unsigned long long)v, off, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) v |= (uint32_t)__shfl_xor((int)v, off, 64);
+    return v;
+}
+// inclusive prefix sum across the wave
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t o = (uint32_t)__shfl_up((int)v, off, 64);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+// OR the low n bits (1..32) of v into the circular bit buffer at absolute bit position pos
+__device__ __forceinline__ void ring_put(uint32_t* ring, uint32_t pos, uint32_t v, int n) {
+    uint32_t w = pos >> 5;
+    int off = (int)(pos & 31);
+    uint64_t t = (((uint64_t)v) << (64 - n)) >> off;
+    uint32_t hi = (uint32_t)(t >> 32), lo = (uint32_t)t;
+    if (hi) atomicOr(&ring[w & kRingMask], hi);
+    if (lo) atomicOr(&ring[(w + 1) & kRingMask], lo);
+}
+
+// Rice partition-order search on the wave: lane p holds the magnitude sum of partition p at
+// order pmax.  Returns estimated bits (incl. 6 bits method+order); best order in *best_po;
+// *kbest = parameter of partition `lane` at the best order.
+__device__ __forceinline__ uint64_t rice_search_wave(uint64_t S, int bs, int pred_order, int pmax, int lane, int* best_po,
+                                                     int* kbest) {
+    uint64_t best = 0;
+    bool have = false;
+    int bpo = 0, kb = 0;
+    for (int po = pmax; po >= 0; --po) {
+        int nparts = 1 << po;
+        uint32_t psz = (uint32_t)(bs >> po);
+        uint64_t pb = 0;
+        int k = 0;
+        if (lane < nparts) {
+            uint32_t n = psz - ((lane == 0) ? (uint32_t)pred_order : 0u);
+            k = rice_param(S, n);
+            pb = rice_part_bits(S, n, k);
+        }
+        uint64_t bits = 6 + wave_sum_u64(pb);
+        if (bits > 0xffffffffULL) bits = 0xffffffffULL;
+        if (!have || bits < best) {
+            have = true;
+            best = bits;
+            bpo = po;
+            kb = k;
+        }
+        uint64_t a = (uint64_t)__shfl((unsigned long long)S, (2 * lane) & 63, 64);
+        uint64_t b = (uint64_t)__shfl((unsigned long long)S, (2 * lane + 1) & 63, 64);
+        S = (lane < (nparts >> 1)) ? (a + b) : 0;
+    }
+    *best_po = bpo;
+    *kbest = kb;
+    return best;
+}
+
+// (Re)load the frame's samples from global memory into the LDS chunk image, applying the
+// wasted-bits shift.  Returns this lane's OR of valid samples and whether all equal `first`.
+__device__ __forceinline__ void load_frame(const int32_t* __restrict__ src, int bs, int wasted, int32_t* smp, int lane,
+                                           uint32_t* orv_out, bool* alleq_out, int32_t first) {
+    const bool aligned = ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+    const int nrows = (bs + kRow - 1) / kRow;
+    uint32_t orv = 0;
+    bool alleq = true;
+    for (int j = 0; j < nrows; ++j) {
+        int base = kRow * j + 4 * lane;
+        int4 v = make_int4(0, 0, 0, 0);
+        if (aligned && base + 3 < bs) {
+            v = *reinterpret_cast<const int4*>(src + base);
+        } else {
+            if (base + 0 < bs) v.x = src[base + 0];
+            if (base + 1 < bs) v.y = src[base + 1];
+            if (base + 2 < bs) v.z = src[base + 2];
+            if (base + 3 < bs) v.w = src[base + 3];
+        }
+        if (base + 0 < bs) { orv |= (uint32_t)v.x; alleq = alleq && (v.x == first); }
+        if (base + 1 < bs) { orv |= (uint32_t)v.y; alleq = alleq && (v.y == first); }
+        if (base + 2 < bs) { orv |= (uint32_t)v.z; alleq = alleq && (v.z == first); }
+        if (base + 3 < bs) { orv |= (uint32_t)v.w; alleq = alleq && (v.w == first); }
+        v.x >>= wasted; v.y >>= wasted; v.z >>= wasted; v.w >>= wasted;
+        *reinterpret_cast<int4*>(&smp[smp_idx(base)]) = v;
+    }
+    *orv_out = orv;
+    *alleq_out = alleq;
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: one wavefront encodes one frame
+// ------------------------------------------------------------------------------------------
+template <int MLO>  // level's maximum LPC order: 0 (fixed predictors only), 6, 8 or 12
+__global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
+    __shared__ __attribute__((aligned(16))) int32_t lds[kLdsWords];
+    int32_t* smp = lds;
+    uint32_t* ring = reinterpret_cast<uint32_t*>(lds + kSmpWords);
+    uint64_t* psum = reinterpret_cast<uint64_t*>(lds + kSmpWords + kRingWords);
+    uint8_t* kpar = reinterpret_cast<uint8_t*>(lds + kSmpWords + kRingWords + 128);
+
+    const int lane = threadIdx.x;
+    const int64_t g = blockIdx.x;
+    const int64_t s = g / a.nframes;
+    const int64_t f = g - s * a.nframes;
+    const int bs = (f == a.nframes - 1) ? a.tail_bs : a.B;
+    const int32_t* src = a.data + s * a.stream_size + f * (int64_t)a.B;
+    const float* win = (bs == a.B) ? a.win : a.win_tail;
+    const int nrows = (bs + kRow - 1) / kRow;
+    const bool active = (kChunk * lane < bs);
+
+    // ---- P0: stage samples, wasted bits, constant test ---------------------------------
+    for (int i = lane; i < kChunkStride; i += 64) smp[i] = 0;  // chunk -1 = zero history
+    const int32_t first = src[0];
+    uint32_t orv;
+    bool alleq;
+    load_frame(src, bs, 0, smp, lane, &orv, &alleq, first);
+    orv = wave_or_u32(orv);
+    const bool is_const = __all(alleq);
+    const int wasted = orv ? (__ffs((int)orv) - 1) : 0;
+    const int bps = 32 - wasted;
+    __syncthreads();
+    if (wasted) {
+        for (int j = 0; j < nrows; ++j) {
+            int4* p = reinterpret_cast<int4*>(&smp[smp_idx(kRow * j + 4 * lane)]);
+            int4 v = *p;
+            v.x >>= wasted; v.y >>= wasted; v.z >>= wasted; v.w >>= wasted;
+            *p = v;
+        }
+        __syncthreads();
+    }
+
+    const uint64_t verbatim_bits = 8 + (uint64_t)wasted + (uint64_t)bs * (uint64_t)bps;
+    int type = 1;  // 0 const, 1 verbatim, 2 fixed, 3 lpc
+    int order = 0, porder = 0, shift = 0, precision = 0;
+    int kbest = 0;           // Rice parameter of partition `lane` for the winner
+    bool lds_is_residual = false;
+    int fo = -1;             // best fixed order
+
+    if (is_const) {
+        type = 0;
+    } else if (bs > 4) {
+        uint64_t best_bits = verbatim_bits;
+
+        // ---- P2: fixed predictors 0..4 over the lane's chunk (exact in double) ---------
+        double tot0 = 0.0, tot1 = 0.0, tot2 = 0.0, tot3 = 0.0, tot4 = 0.0;
+        double mx0 = 0.0, mx1 = 0.0, mx2 = 0.0, mx3 = 0.0, mx4 = 0.0;
+        if (active) {
+            const int cbase = kChunkStride * (lane + 1);
+            int4 h = *reinterpret_cast<const int4*>(&smp[cbase - kChunkStride + 60]);
+            double p1 = (double)h.w;
+            double pe1 = (double)h.w - (double)h.z;
+            double e1b = (double)h.z - (double)h.y;
+            double pe2 = pe1 - e1b;
+            double e2b = e1b - ((double)h.y - (double)h.x);
+            double pe3 = pe2 - e2b;
+            const int g0 = kChunk * lane;
+#pragma unroll 4
+            for (int t = 0; t < 16; ++t) {
+                int4 xv = *reinterpret_cast<const int4*>(&smp[cbase + 4 * t]);
+                int xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int gi = g0 + 4 * t + e;
+                    const double xd = (double)xs[e];
+                    const double e1 = xd - p1;
+                    const double e2 = e1 - pe1;
+                    const double e3 = e2 - pe2;
+                    const double e4 = e3 - pe3;
+                    const bool v = gi < bs;
+                    const double a0 = v ? fa_fabs(xd) : 0.0;
+                    const double a1 = (v && gi >= 1) ? fa_fabs(e1) : 0.0;
+                    const double a2 = (v && gi >= 2) ? fa_fabs(e2) : 0.0;
+                    const double a3 = (v && gi >= 3) ? fa_fabs(e3) : 0.0;
+                    const double a4 = (v && gi >= 4) ? fa_fabs(e4) : 0.0;
+                    tot0 += a0; tot1 += a1; tot2 += a2; tot3 += a3; tot4 += a4;
+                    mx0 = a0 > mx0 ? a0 : mx0;
+                    mx1 = a1 > mx1 ? a1 : mx1;
+                    mx2 = a2 > mx2 ? a2 : mx2;
+                    mx3 = a3 > mx3 ? a3 : mx3;
+                    mx4 = a4 > mx4 ? a4 : mx4;
+                    p1 = xd; pe1 = e1; pe2 = e2; pe3 = e3;
+                }
+            }
+        }
+        {
+            const double T0 = wave_sum_butterfly(tot0), T1 = wave_sum_butterfly(tot1), T2 = wave_sum_butterfly(tot2),
+                         T3 = wave_sum_butterfly(tot3), T4 = wave_sum_butterfly(tot4);
+            const double M0 = wave_max_f64(mx0), M1 = wave_max_f64(mx1), M2 = wave_max_f64(mx2), M3 = wave_max_f64(mx3),
+                         M4 = wave_max_f64(mx4);
+            const double lim = 2147483647.0;
+            double smallest = 1.8446744073709552e19;  // 2^64, above any total
+            if (M0 <= lim && T0 < smallest) { fo = 0; smallest = T0; }
+            if (M1 <= lim && T1 < smallest) { fo = 1; smallest = T1; }
+            if (M2 <= lim && T2 < smallest) { fo = 2; smallest = T2; }
+            if (M3 <= lim && T3 < smallest) { fo = 3; smallest = T3; }
+            if (M4 <= lim && T4 < smallest) { fo = 4; smallest = T4; }
+        }
+        int po_fix = 0, k_fix = 0;
+        if (fo >= 0) {
+            const double tl = (fo == 0) ? tot0 : (fo == 1) ? tot1 : (fo == 2) ? tot2 : (fo == 3) ? tot3 : tot4;
+            const int pmax = max_porder_for(bs, a.max_porder, fo);
+            const int lpp = (pmax == 0) ? 64 : ((bs >> pmax) / kChunk);
+            psum[lane] = 0;
+            __syncthreads();
+            if (active) atomicAdd(reinterpret_cast<unsigned long long*>(&psum[lane / lpp]), (unsigned long long)tl);
+            __syncthreads();
+            const uint64_t S = psum[lane];
+            const uint64_t est = 8 + (uint64_t)wasted + (uint64_t)fo * (uint64_t)bps +
+                                 rice_search_wave((lane < (1 << pmax)) ? S : 0, bs, fo, pmax, lane, &po_fix, &k_fix);
+            if (est < best_bits) {
+                best_bits = est;
+                type = 2;
+                order = fo;
+                porder = po_fix;
+                kbest = k_fix;
+            }
+            __syncthreads();
+        }
+
+        // ---- P3: LPC analysis ----------------------------------------------------------
+        if constexpr (MLO > 0) {
+            int mlo = a.max_lpc_order;
+            if (mlo > bs - 1) mlo = bs - 1;
+            if (mlo > 0) {
+                double acc[MLO + 1];
+#pragma unroll
+                for (int j = 0; j <= MLO; ++j) acc[j] = 0.0;
+                if (active) {
+                    const int cbase = kChunkStride * (lane + 1);
+                    const int g0 = kChunk * lane;
+                    double hist[MLO];  // hist[j] = d[i-1-j]
+#pragma unroll
+                    for (int j = 0; j < MLO; ++j) {
+                        const int gi = g0 - 1 - j;
+                        const int xi = smp[cbase - kChunkStride + 63 - j];
+                        const float wv = (gi >= 0) ? win[gi] : 0.0f;
+                        hist[j] = (double)xi * (double)wv;
+                    }
+#pragma unroll 4
+                    for (int t = 0; t < 16; ++t) {
+                        int4 xv = *reinterpret_cast<const int4*>(&smp[cbase + 4 * t]);
+                        int xs[4] = {xv.x, xv.y, xv.z, xv.w};
+                        float ws[4];
+                        const int gb = g0 + 4 * t;
+                        if (gb + 3 < bs) {
+                            float4 wv = *reinterpret_cast<const float4*>(win + gb);
+                            ws[0] = wv.x; ws[1] = wv.y; ws[2] = wv.z; ws[3] = wv.w;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) ws[e] = (gb + e < bs) ? win[gb + e] : 0.0f;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const double d = (double)xs[e] * (double)ws[e];
+                            acc[0] = __builtin_fma(d, d, acc[0]);
+#pragma unroll
+                            for (int j = 0; j < MLO; ++j) acc[j + 1] = __builtin_fma(d, hist[j], acc[j + 1]);
+#pragma unroll
+                            for (int j = MLO - 1; j > 0; --j) hist[j] = hist[j - 1];
+                            hist[0] = d;
+                        }
+                    }
+                }
+                double autoc[MLO + 1];
+#pragma unroll
+                for (int j = 0; j <= MLO; ++j) autoc[j] = wave_sum_butterfly(acc[j]);
+
+                if (autoc[0] != 0.0) {
+                    // scratch in the (still unused) ring area
+                    float* coef = reinterpret_cast<float*>(ring);               // MLO*MLO floats
+                    double* err = reinterpret_cast<double*>(ring + 160);        // MLO doubles
+                    int32_t* qc = reinterpret_cast<int32_t*>(ring + 200);       // MLO ints
+                    int* meta = reinterpret_cast<int*>(ring + 220);             // ok, lo, prec, shift
+                    if (lane == 0) {
+                        int usable = levinson<MLO>(autoc, mlo, coef, err);
+                        int prec = a.precision;
+                        int lo = best_lpc_order(err, usable, bs, bps + prec);
+                        if (bps <= 17) {
+                            int limp = 32 - bps - ilog2_u64((uint64_t)lo);
+                            if (prec > limp) prec = limp;
+                        }
+                        int sh = 0;
+                        int ok = 0;
+                        if (prec >= 2) ok = (quantize_coefs(coef + (lo - 1) * MLO, lo, prec, qc, &sh) == 0) ? 1 : 0;
+                        for (int j = lo; j < MLO; ++j) qc[j] = 0;
+                        meta[0] = ok; meta[1] = lo; meta[2] = prec; meta[3] = sh;
+                    }
+                    __syncthreads();
+                    const int ok = meta[0], lo = meta[1], prec = meta[2], sh = meta[3];
+                    if (ok) {
+                        double qd[MLO];
+#pragma unroll
+                        for (int j = 0; j < MLO; ++j) qd[j] = (double)qc[j];
+                        // ---- P4: LPC residual in place + magnitude sums ----------------
+                        double tl = 0.0, mxr = 0.0;
+                        const double scale = bitsd((uint64_t)(1023 - sh) << 52);  // 2^-sh
+                        if (active) {
+                            const int cbase = kChunkStride * (lane + 1);
+                            const int g0 = kChunk * lane;
+                            double hx[MLO];
+#pragma unroll
+                            for (int j = 0; j < MLO; ++j) hx[j] = (double)smp[cbase - kChunkStride + 63 - j];
+#pragma unroll 4
+                            for (int t = 0; t < 16; ++t) {
+                                int4* px = reinterpret_cast<int4*>(&smp[cbase + 4 * t]);
+                                int4 xv = *px;
+                                int xs[4] = {xv.x, xv.y, xv.z, xv.w};
+                                int rs[4];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const int gi = g0 + 4 * t + e;
+                                    const double xd = (double)xs[e];
+                                    double sum = 0.0;
+#pragma unroll
+                                    for (int j = 0; j < MLO; ++j) sum = __builtin_fma(qd[j], hx[j], sum);
+                                    const double pred = fa_floor(sum * scale);
+                                    const double r = xd - pred;
+                                    const bool v = (gi < bs) && (gi >= lo);
+                                    const double ar = v ? fa_fabs(r) : 0.0;
+                                    tl += ar;
+                                    mxr = ar > mxr ? ar : mxr;
+                                    rs[e] = v ? (int)r : xs[e];
+#pragma unroll
+                                    for (int j = MLO - 1; j > 0; --j) hx[j] = hx[j - 1];
+                                    hx[0] = xd;
+                                }
+                                *px = make_int4(rs[0], rs[1], rs[2], rs[3]);
+                            }
+                        }
+                        lds_is_residual = true;
+                        const double MX = wave_max_f64(mxr);
+                        const int pmax = max_porder_for(bs, a.max_porder, lo);
+                        const int lpp = (pmax == 0) ? 64 : ((bs >> pmax) / kChunk);
+                        __syncthreads();
+                        psum[lane] = 0;
+                        __syncthreads();
+                        if (active) atomicAdd(reinterpret_cast<unsigned long long*>(&psum[lane / lpp]), (unsigned long long)tl);
+                        __syncthreads();
+                        const uint64_t S = psum[lane];
+                        int po_l = 0, k_l = 0;
+                        const uint64_t rbits = rice_search_wave((lane < (1 << pmax)) ? S : 0, bs, lo, pmax, lane, &po_l, &k_l);
+                        if (MX <= 2147483647.0) {
+                            const uint64_t est = 8 + (uint64_t)wasted + 4 + 5 + (uint64_t)lo * (uint64_t)(prec + bps) + rbits;
+                            if (est < best_bits) {
+                                best_bits = est;
+                                type = 3;
+                                order = lo;
+                                porder = po_l;
+                                kbest = k_l;
+                                shift = sh;
+                                precision = prec;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+    }
+
+    // LPC coefficients must survive the ring being recycled: keep them in registers
+    int32_t qkeep[(MLO > 0) ? MLO : 1];
+    if constexpr (MLO > 0) {
+        const int32_t* qc = reinterpret_cast<const int32_t*>(ring + 200);
+#pragma unroll
+        for (int j = 0; j < MLO; ++j) qkeep[j] = (type == 3) ? qc[j] : 0;
+    }
+    __syncthreads();
+
+    // ---- emit (with one possible VERBATIM retry) ---------------------------------------
+    uint8_t* slot = a.slots + (size_t)g * kSlotBytes;
+    uint32_t total_bytes = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        // make the LDS image hold what this subframe type needs
+        if (type == 3) {
+            // residual already in place
+        } else {
+            if (lds_is_residual) {
+                uint32_t o2; bool e2;
+                load_frame(src, bs, wasted, smp, lane, &o2, &e2, first);
+                lds_is_residual = false;
+                __syncthreads();
+            }
+            if (type == 2 && order > 0) {
+                // fixed residual of order `order`, in place (history read before any write)
+                if (active) {
+                    const int cbase = kChunkStride * (lane + 1);
+                    const int g0 = kChunk * lane;
+                    int4 h = *reinterpret_cast<const int4*>(&smp[cbase - kChunkStride + 60]);
+                    int64_t x1 = h.w, x2 = h.z, x3 = h.y, x4 = h.x;
+                    for (int t = 0; t < 16; ++t) {
+                        int4* px = reinterpret_cast<int4*>(&smp[cbase + 4 * t]);
+                        int4 xv = *px;
+                        int xs[4] = {xv.x, xv.y, xv.z, xv.w};
+                        int rs[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int gi = g0 + 4 * t + e;
+                            const int64_t x0 = xs[e];
+                            int64_t r;
+                            if (order == 1) r = x0 - x1;
+                            else if (order == 2) r = x0 - 2 * x1 + x2;
+                            else if (order == 3) r = x0 - 3 * x1 + 3 * x2 - x3;
+                            else r = x0 - 4 * x1 + 6 * x2 - 4 * x3 + x4;
+                            rs[e] = (gi >= order && gi < bs) ? (int)r : xs[e];
+                            x4 = x3; x3 = x2; x2 = x1; x1 = x0;
+                        }
+                        *px = make_int4(rs[0], rs[1], rs[2], rs[3]);
+                    }
+                }
+                lds_is_residual = true;
+            }
+        }
+        // Rice parameter table and ring reset
+        kpar[lane] = (uint8_t)kbest;
+        for (int i = lane; i < kRingWords; i += 64) ring[i] = 0;
+        __syncthreads();
+
+        bool rice2 = false;
+        if (type >= 2) rice2 = __any((lane < (1 << porder)) && (kbest >= 15));
+        const int plen = rice2 ? 5 : 4;
+
+        // ---- preamble by lane 0: frame header, subframe header, warm-up, LPC fields ----
+        uint32_t pos = 0;
+        if (lane == 0) {
+            uint8_t hdr[16];
+            int nh = 0;
+            const int bsc = blocksize_code(bs);
+            hdr[nh++] = 0xFF;
+            hdr[nh++] = 0xF8;
+            hdr[nh++] = (uint8_t)((bsc << 4) | 9);
+            hdr[nh++] = 0x0E;  // mono, 32 bits per sample, reserved 0
+            const uint64_t fn = (uint64_t)f;
+            if (fn < 0x80) hdr[nh++] = (uint8_t)fn;
+            else if (fn < 0x800) { hdr[nh++] = (uint8_t)(0xC0 | (fn >> 6)); hdr[nh++] = (uint8_t)(0x80 | (fn & 0x3F)); }
+            else if (fn < 0x10000) { hdr[nh++] = (uint8_t)(0xE0 | (fn >> 12)); hdr[nh++] = (uint8_t)(0x80 | ((fn >> 6) & 0x3F)); hdr[nh++] = (uint8_t)(0x80 | (fn & 0x3F)); }
+            else if (fn < 0x200000) { hdr[nh++] = (uint8_t)(0xF0 | (fn >> 18)); hdr[nh++] = (uint8_t)(0x80 | ((fn >> 12) & 0x3F)); hdr[nh++] = (uint8_t)(0x80 | ((fn >> 6) & 0x3F)); hdr[nh++] = (uint8_t)(0x80 | (fn & 0x3F)); }
+            else if (fn < 0x4000000) { hdr[nh++] = (uint8_t)(0xF8 | (fn >> 24)); hdr[nh++] = (uint8_t)(0x80 | ((fn >> 18) & 0x3F)); hdr[nh++] = (uint8_t)(0x80 | ((fn >> 12) & 0x3F)); hdr[nh++] = (uint8_t)(0x80 | ((fn >> 6) & 0x3F)); hdr[nh++] = (uint8_t)(0x80 | (fn & 0x3F)); }
+            else { hdr[nh++] = (uint8_t)(0xFC | (fn >> 30)); hdr[nh++] = (uint8_t)(0x80 | ((fn >> 24) & 0x3F)); hdr[nh++] = (uint8_t)(0x80 | ((fn >> 18) & 0x3F)); hdr[nh++] = (uint8_t)(0x80 | ((fn >> 12) & 0x3F)); hdr[nh++] = (uint8_t)(0x80 | ((fn >> 6) & 0x3F)); hdr[nh++] = (uint8_t)(0x80 | (fn & 0x3F)); }
+            if (bsc == 6) hdr[nh++] = (uint8_t)(bs - 1);
+            else if (bsc == 7) { hdr[nh++] = (uint8_t)((bs - 1) >> 8); hdr[nh++] = (uint8_t)(bs - 1); }
+            uint8_t c8 = 0;
+            for (int i = 0; i < nh; ++i) c8 = crc8_byte(c8, hdr[i]);
+            hdr[nh++] = c8;
+            for (int i = 0; i < nh; ++i) { ring_put(ring, pos, hdr[i], 8); pos += 8; }
+            // subframe header
+            int tc = (type == 0) ? 0x00 : (type == 1) ? 0x01 : (type == 2) ? (0x08 | order) : (0x20 | (order - 1));
+            ring_put(ring, pos, (uint32_t)((tc << 1) | (wasted ? 1 : 0)), 8); pos += 8;
+            if (wasted) { pos += (uint32_t)(wasted - 1); ring_put(ring, pos, 1, 1); pos += 1; }
+            const uint32_t mask = (bps == 32) ? 0xffffffffu : ((1u << bps) - 1u);
+            if (type == 0) {
+                ring_put(ring, pos, (uint32_t)smp[smp_idx(0)] & mask, bps); pos += (uint32_t)bps;
+            } else if (type >= 2) {
+                for (int i = 0; i < order; ++i) { ring_put(ring, pos, (uint32_t)smp[smp_idx(i)] & mask, bps); pos += (uint32_t)bps; }
+                if (type == 3) {
+                    ring_put(ring, pos, (uint32_t)(precision - 1), 4); pos += 4;
+                    ring_put(ring, pos, (uint32_t)shift, 5); pos += 5;
+                }
+            }
+        }
+        if constexpr (MLO > 0) {
+            if (type == 3) {
+                // coefficients live in registers (compile-time indices): lane 0 appends them
+                pos = (uint32_t)__shfl((int)pos, 0, 64);
+#pragma unroll
+                for (int j = 0; j < MLO; ++j) {
+                    if (j < order) {
+                        if (lane == 0) ring_put(ring, pos, (uint32_t)qkeep[j] & ((1u << precision) - 1u), precision);
+                        pos += (uint32_t)precision;
+                    }
+                }
+            }
+        }
+        if (lane == 0 && type >= 2) {
+            ring_put(ring, pos, rice2 ? 1u : 0u, 2); pos += 2;
+            ring_put(ring, pos, (uint32_t)porder, 4); pos += 4;
+        }
+        pos = (uint32_t)__shfl((int)pos, 0, 64);
+        const uint32_t hdr_bits = (uint32_t)__shfl((int)0, 0, 64);  // placeholder to keep pos uniform
+        (void)hdr_bits;
+        __syncthreads();
+
+        // frame header bit count (needed for the exact subframe size): 8*(4 + utf8 + bs bytes + 1)
+        uint32_t fh_bits;
+        {
+            const uint64_t fn = (uint64_t)f;
+            int nb = (fn < 0x80) ? 1 : (fn < 0x800) ? 2 : (fn < 0x10000) ? 3 : (fn < 0x200000) ? 4 : (fn < 0x4000000) ? 5 : 6;
+            const int bsc = blocksize_code(bs);
+            fh_bits = 8u * (uint32_t)(4 + nb + (bsc == 6 ? 1 : bsc == 7 ? 2 : 0) + 1);
+        }
+
+        // ---- rows: 4 consecutive samples per lane, scan of code lengths, OR into the ring ----
+        bool overflow = false;
+        uint32_t blocks_flushed = 0;
+        if (type != 0) {
+            const uint32_t ps = (uint32_t)(bs >> porder);
+            const uint32_t magic = (uint32_t)((0x100000000ULL + ps - 1) / ps);  // floor(gi/ps) = umulhi(gi, magic)
+            const uint32_t mask = (bps == 32) ? 0xffffffffu : ((1u << bps) - 1u);
+            for (int j = 0; j < nrows; ++j) {
+                const int gb = kRow * j + 4 * lane;
+                int4 rv = *reinterpret_cast<const int4*>(&smp[smp_idx(gb)]);
+                int rs[4] = {rv.x, rv.y, rv.z, rv.w};
+                uint32_t ilen[4], iq[4], ival[4], ipre[4];
+                int inb[4];
+                uint32_t lane_len = 0;
+                int k = 0;
+                uint32_t pidx = 0;
+                if (type >= 2) {
+                    pidx = __umulhi((uint32_t)gb, magic);
+                    k = kpar[pidx];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int gi = gb + e;
+                    ilen[e] = 0; iq[e] = 0; ival[e] = 0; ipre[e] = 0; inb[e] = 0;
+                    if (gi < bs) {
+                        if (type == 1) {
+                            inb[e] = bps;
+                            ival[e] = (uint32_t)rs[e] & mask;
+                            ilen[e] = (uint32_t)bps;
+                        } else if (gi >= order) {
+                            const uint32_t u = ((uint32_t)rs[e] << 1) ^ (uint32_t)(rs[e] >> 31);
+                            iq[e] = u >> k;
+                            inb[e] = k + 1;
+                            ival[e] = (1u << k) | (u & ((1u << k) - 1u));
+                            const uint32_t pstart = (pidx == 0) ? (uint32_t)order : pidx * ps;
+                            ipre[e] = ((uint32_t)gi == pstart) ? (uint32_t)plen : 0u;
+                            ilen[e] = ipre[e] + iq[e] + (uint32_t)k + 1u;
+                        }
+                    }
+                    lane_len += ilen[e];
+                }
+                const uint32_t incl = wave_incl_scan_u32(lane_len, lane);
+                const uint32_t row_total = (uint32_t)__shfl((int)incl, 63, 64);
+                if (type >= 2 && row_total > (uint32_t)kRowCapBits) { overflow = true; break; }
+                uint32_t p = pos + incl - lane_len;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (ilen[e]) {
+                        if (ipre[e]) { ring_put(ring, p, (uint32_t)k, plen); p += ipre[e]; }
+                        p += iq[e];
+                        ring_put(ring, p, ival[e], inb[e]);
+                        p += (uint32_t)inb[e];
+                    }
+                }
+                pos += row_total;
+                __syncthreads();
+                // flush completed 256-byte blocks
+                const uint32_t done = pos >> 11;
+                while (blocks_flushed < done) {
+                    const uint32_t wi = (blocks_flushed * 64 + lane) & kRingMask;
+                    const uint32_t wv = ring[wi];
+                    ring[wi] = 0;
+                    reinterpret_cast<uint32_t*>(slot)[blocks_flushed * 64 + lane] = __builtin_bswap32(wv);
+                    blocks_flushed++;
+                }
+                __syncthreads();
+            }
+        }
+        if (!overflow && type >= 2) {
+            const uint64_t exact = (uint64_t)pos - fh_bits;
+            if (exact > verbatim_bits) overflow = true;
+        }
+        if (overflow) {
+            type = 1;
+            order = 0;
+            porder = 0;
+            continue;  // second attempt writes the VERBATIM subframe
+        }
+        // ---- tail: byte align, 16 zero bits for the CRC-16 (filled in by K5), final flush ----
+        pos = (pos + 7u) & ~7u;
+        pos += 16;
+        total_bytes = pos >> 3;
+        const uint32_t nwords = (total_bytes + 3) >> 2;
+        for (uint32_t w0 = blocks_flushed * 64; w0 < nwords; w0 += 64) {
+            const uint32_t wl = w0 + lane;
+            if (wl < nwords) reinterpret_cast<uint32_t*>(slot)[wl] = __builtin_bswap32(ring[wl & kRingMask]);
+        }
+        break;
+    }
+    if (lane == 0) {
+        a.frame_bytes[g] = total_bytes;
+        if (a.info) {
+            FrameInfo fi;
+            fi.type = type;
+            fi.order = (type >= 2) ? order : 0;
+            fi.porder = (type >= 2) ? porder : 0;
+            fi.wasted = wasted;
+            fi.shift = (type == 3) ? shift : 0;
+            fi.precision = (type == 3) ? precision : 0;
+            fi.nbytes = (int32_t)total_bytes;
+            fi.blocksize = bs;
+            a.info[g] = fi;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: sizes -> offsets
+// ------------------------------------------------------------------------------------------
+// one 256-thread block per stream: exclusive scan of its frame sizes
+__global__ __launch_bounds__(256) void stream_scan_kernel(const uint32_t* __restrict__ frame_bytes, int64_t nframes,
+                                                          int64_t* __restrict__ frame_off, int64_t* __restrict__ stream_nbytes) {
+    __shared__ uint64_t sh[256];
+    __shared__ uint64_t carry;
+    const int64_t s = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nframes; base += 256) {
+        const int64_t f = base + tid;
+        const uint64_t v = (f < nframes) ? frame_bytes[s * nframes + f] : 0;
+        sh[tid] = v;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            uint64_t t = (tid >= off) ? sh[tid - off] : 0;
+            __syncthreads();
+            sh[tid] += t;
+            __syncthreads();
+        }
+        const uint64_t c = carry;
+        if (f < nframes) frame_off[s * nframes + f] = (int64_t)(c + sh[tid] - v);
+        __syncthreads();
+        if (tid == 255) carry = c + sh[255];
+        __syncthreads();
+    }
+    if (tid == 0) stream_nbytes[s] = (int64_t)carry + stream_header_bytes(nframes);
+}
+
+// single 1024-thread block: exclusive scan of stream sizes -> starts, total
+__global__ __launch_bounds__(1024) void starts_scan_kernel(const int64_t* __restrict__ stream_nbytes, int64_t n_stream,
+                                                           int64_t* __restrict__ starts, int64_t* __restrict__ total) {
+    __shared__ uint64_t sh[1024];
+    __shared__ uint64_t carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n_stream; base += 1024) {
+        const int64_t i = base + tid;
+        const uint64_t v = (i < n_stream) ? (uint64_t)stream_nbytes[i] : 0;
+        sh[tid] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            uint64_t t = (tid >= off) ? sh[tid - off] : 0;
+            __syncthreads();
+            sh[tid] += t;
+            __syncthreads();
+        }
+        const uint64_t c = carry;
+        if (i < n_stream) starts[i] = (int64_t)(c + sh[tid] - v);
+        __syncthreads();
+        if (tid == 1023) carry = c + sh[1023];
+        __syncthreads();
+    }
+    if (tid == 0) *total = (int64_t)carry;
+}
+
+// ------------------------------------------------------------------------------------------
+// K5a: stream headers.  One 256-thread block per stream.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void write_headers_kernel(uint8_t* __restrict__ out, const int64_t* __restrict__ starts,
+                                                            const int64_t* __restrict__ frame_off, int64_t nframes,
+                                                            int64_t stream_size, int32_t B, int32_t tail_bs) {
+    const int64_t s = blockIdx.x;
+    uint8_t* h = out + starts[s];
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        h[0] = 'f'; h[1] = 'L'; h[2] = 'a'; h[3] = 'C';
+        h[4] = 0x00; h[5] = 0; h[6] = 0; h[7] = 34;
+        uint8_t* si = h + 8;
+        si[0] = (uint8_t)(B >> 8); si[1] = (uint8_t)B; si[2] = (uint8_t)(B >> 8); si[3] = (uint8_t)B;
+        for (int i = 4; i < 10; ++i) si[i] = 0;
+        const uint64_t ts = ((uint64_t)stream_size < (1ULL << 36)) ? (uint64_t)stream_size : 0;
+        const uint64_t packed = ((uint64_t)44100 << 44) | ((uint64_t)31 << 36) | ts;
+        for (int i = 0; i < 8; ++i) si[10 + i] = (uint8_t)(packed >> (56 - 8 * i));
+        for (int i = 18; i < 34; ++i) si[i] = 0;
+        uint8_t* t = h + 42;
+        const uint32_t stl = (uint32_t)(18 * nframes);
+        t[0] = 0x83; t[1] = (uint8_t)(stl >> 16); t[2] = (uint8_t)(stl >> 8); t[3] = (uint8_t)stl;
+    }
+    for (int64_t f = tid; f < nframes; f += 256) {
+        uint8_t* p = h + 46 + 18 * f;
+        const uint64_t sn = (uint64_t)f * (uint64_t)B;
+        const uint64_t off = (uint64_t)frame_off[s * nframes + f];
+        const int bs = (f == nframes - 1) ? tail_bs : B;
+        for (int i = 0; i < 8; ++i) { p[i] = (uint8_t)(sn >> (56 - 8 * i)); p[8 + i] = (uint8_t)(off >> (56 - 8 * i)); }
+        p[16] = (uint8_t)(bs >> 8);
+        p[17] = (uint8_t)bs;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K5b: move every frame from its slot to its final byte offset and fill in its CRC-16.
+// One wavefront per frame, grid-stride; CRC tables (computed on the host once) live in LDS.
+//   tab[0..1023]   slicing tables: crc contribution of byte k (k=0 most significant) of a word
+//   tab[1024..1535] Z256 hi/lo: state advanced by 256 zero bytes
+//   tab[1536..2047] xpow[n] = x^(8n) mod P, n < 512
+// ------------------------------------------------------------------------------------------
+constexpr int kCrcTabWords = 2048;  // uint16 entries
+
+__device__ __forceinline__ uint16_t crc_mulmod(uint16_t a, uint16_t b) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 15; i >= 0; --i) {
+        r = (r << 1) ^ ((r & 0x8000u) ? 0x18005u : 0u);
+        if ((b >> i) & 1) r ^= a;
+    }
+    return (uint16_t)r;
+}
+
+__global__ __launch_bounds__(256) void compact_frames_kernel(const uint8_t* __restrict__ slots,
+                                                             const uint32_t* __restrict__ frame_bytes,
+                                                             const int64_t* __restrict__ frame_off,
+                                                             const int64_t* __restrict__ starts, int64_t nframes,
+                                                             int64_t total_frames, const uint16_t* __restrict__ crc_tab,
+                                                             uint8_t* __restrict__ out) {
+    __shared__ uint16_t tab[kCrcTabWords];
+    for (int i = threadIdx.x; i < kCrcTabWords; i += 256) tab[i] = crc_tab[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t hb = stream_header_bytes(nframes);
+    for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < total_frames; g += (int64_t)gridDim.x * 4) {
+        const int64_t s = g / nframes;
+        const uint32_t n = frame_bytes[g];
+        const uint32_t* srcw = reinterpret_cast<const uint32_t*>(slots + (size_t)g * kSlotBytes);
+        const uint8_t* srcb = reinterpret_cast<const uint8_t*>(srcw);
+        uint8_t* dst = out + starts[s] + hb + frame_off[g];
+        const uint32_t L = n - 2;  // bytes covered by the CRC
+        // ---- CRC-16 over src bytes [0, L) ----
+        const uint32_t NB = (L + 255) >> 8;
+        uint16_t t = 0;
+        uint32_t last_full = 0;  // number of blocks in which this lane held a full word
+        uint16_t partial = 0;
+        for (uint32_t b = 0; b < NB; ++b) {
+            const uint32_t o = 256u * b + 4u * (uint32_t)lane;
+            if (o + 4 <= L) {
+                const uint32_t w = srcw[o >> 2];  // little-endian load: byte o is the low byte
+                const uint16_t adv = (uint16_t)(tab[1024 + (t >> 8)] ^ tab[1280 + (t & 255)]);
+                const uint16_t c = (uint16_t)(tab[w & 255] ^ tab[256 + ((w >> 8) & 255)] ^ tab[512 + ((w >> 16) & 255)] ^ tab[768 + (w >> 24)]);
+                t = (uint16_t)(adv ^ c);
+                last_full = b + 1;
+            } else if (o < L) {
+                uint16_t c = 0;
+                for (uint32_t i = o; i < L; ++i) c = crc16_byte(c, srcb[i]);
+                partial = c;
+            }
+        }
+        uint16_t contrib = partial;
+        if (last_full > 0) {
+            const uint32_t after = L - (256u * (last_full - 1) + 4u * (uint32_t)lane + 4u);  // bytes after the lane's last word
+            contrib ^= crc_mulmod(t, tab[1536 + after]);
+        }
+        uint32_t cr = contrib;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) cr ^= (uint32_t)__shfl_xor((int)cr, off, 64);
+        const uint16_t crc = (uint16_t)cr;
+        // ---- byte-shifted copy: destination-aligned words ----
+        const uint32_t head = (uint32_t)((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3);
+        const uint32_t hcopy = head < n ? head : n;
+        if ((uint32_t)lane < hcopy) {
+            uint8_t v = srcb[lane];
+            if ((uint32_t)lane == n - 2) v = (uint8_t)(crc >> 8);
+            if ((uint32_t)lane == n - 1) v = (uint8_t)crc;
+            dst[lane] = v;
+        }
+        const uint32_t nw = (n - hcopy) >> 2;
+        uint32_t* dstw = reinterpret_cast<uint32_t*>(dst + hcopy);
+        const uint32_t sh = hcopy & 3;  // source misalignment of every destination word
+        for (uint32_t w0 = 0; w0 < nw; w0 += 64) {
+            const uint32_t w = w0 + lane;
+            if (w < nw) {
+                const uint32_t o = hcopy + 4 * w;  // source byte offset
+                const uint32_t a0 = srcw[o >> 2];
+                uint32_t v = a0;
+                if (sh) {
+                    const uint32_t a1 = srcw[(o >> 2) + 1];
+                    v = __builtin_amdgcn_alignbyte(a1, a0, sh);
+                }
+                // patch CRC bytes that fall inside this word
+                if (o + 4 > n - 2) {
+                    for (uint32_t i = 0; i < 4; ++i) {
+                        const uint32_t bo = o + i;
+                        if (bo == n - 2) v = (v & ~(0xffu << (8 * i))) | ((uint32_t)(crc >> 8) << (8 * i));
+                        if (bo == n - 1) v = (v & ~(0xffu << (8 * i))) | ((uint32_t)(crc & 0xff) << (8 * i));
+                    }
+                }
+                dstw[w] = v;
+            }
+        }
+        const uint32_t tail0 = hcopy + 4 * nw;
+        if (tail0 + (uint32_t)lane < n) {
+            const uint32_t bo = tail0 + lane;
+            uint8_t v = srcb[bo];
+            if (bo == n - 2) v = (uint8_t)(crc >> 8);
+            if (bo == n - 1) v = (uint8_t)crc;
+            dst[bo] = v;
+        }
+    }
+}
+
+}  // namespace fa

@@ -1,0 +1,92 @@
+"""Multi-GPU sharding of the encode/decode path: one process per GPU, torch.distributed.
+
+Streams are independent, so the leading axis is split into contiguous ranges exactly as the
+reference's MPI layer does (np.array_split semantics, src/flacarray/mpi.py:84-90); every rank
+encodes / decodes its own shard with no data-path collective.  The only exchange step is the
+optional assembly of the global (compressed, stream_starts, stream_nbytes) triple:
+
+  1. all-gather of the per-stream byte counts (fixed size per rank after padding) -- the
+     analogue of `allgather(local_nbytes)` in mpi.py:177 -- followed by an exclusive scan, which
+     reproduces `global_bytes` (mpi.py:156-187);
+  2. an all-gather-v of the shard blobs.  RCCL has no AllGatherv; xGMI is a fully connected
+     point-to-point mesh, so each rank posts one send and one receive per peer in a single
+     batch (grouped ncclSend/ncclRecv), every transfer on its own link, written straight to
+     the rank's offset in the global blob.
+
+Works with backend "nccl" (= RCCL, device tensors) and "gloo" (CPU tensors; used by the tests).
+"""
+import numpy as np
+
+
+def shard_range(n_stream, world_size, rank):
+    """[lo, hi) of the leading-axis rows owned by `rank` (np.array_split semantics, mpi.py:84-90)."""
+    base, rem = divmod(int(n_stream), int(world_size))
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo, hi
+
+
+def shard_counts(n_stream, world_size):
+    return [shard_range(n_stream, world_size, r)[1] - shard_range(n_stream, world_size, r)[0] for r in range(world_size)]
+
+
+def gather_stream_nbytes(local_nbytes, n_stream_global, group=None):
+    """All-gather the per-stream byte counts; returns (global nbytes int64[n_stream_global],
+    global starts int64[n_stream_global], per-rank byte totals list)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    counts = shard_counts(n_stream_global, world)
+    maxc = max(counts)
+    dev = local_nbytes.device
+    padded = torch.zeros(maxc, dtype=torch.int64, device=dev)
+    padded[: local_nbytes.numel()] = local_nbytes.reshape(-1)
+    gathered = torch.empty(world * maxc, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(gathered, padded, group=group)
+    gathered = gathered.reshape(world, maxc)
+    parts = [gathered[r, : counts[r]] for r in range(world)]
+    g_nbytes = torch.cat(parts)
+    g_starts = torch.cumsum(g_nbytes, 0) - g_nbytes  # exclusive scan == global_bytes(), mpi.py:181-186
+    rank_bytes = [int(p.sum().item()) for p in parts]
+    return g_nbytes, g_starts, rank_bytes
+
+
+def all_gather_blobs(local_blob, rank_bytes, group=None):
+    """All-gather-v of uint8 blobs: returns the concatenation over ranks on every rank.
+
+    One batched round of point-to-point transfers (each rank -> every peer), receives landing
+    directly at the rank's byte offset of the output.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    offs = np.concatenate([[0], np.cumsum(rank_bytes)]).astype(np.int64)
+    out = torch.empty(int(offs[-1]), dtype=torch.uint8, device=local_blob.device)
+    out[int(offs[rank]) : int(offs[rank + 1])] = local_blob
+    if world == 1:
+        return out
+    ops = []
+    for step in range(1, world):
+        dst = (rank + step) % world
+        src = (rank - step) % world
+        gdst = dist.get_global_rank(group, dst) if group is not None else dst
+        gsrc = dist.get_global_rank(group, src) if group is not None else src
+        if rank_bytes[rank] > 0:
+            ops.append(dist.P2POp(dist.isend, local_blob, gdst, group))
+        if rank_bytes[src] > 0:
+            ops.append(dist.P2POp(dist.irecv, out[int(offs[src]) : int(offs[src + 1])], gsrc, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return out
+
+
+def assemble_global(local_blob, local_nbytes, n_stream_global, group=None):
+    """Global (compressed, stream_starts, stream_nbytes) on every rank, bit-identical to a
+    single-process encode of the whole array."""
+    g_nbytes, g_starts, rank_bytes = gather_stream_nbytes(local_nbytes, n_stream_global, group)
+    blob = all_gather_blobs(local_blob, rank_bytes, group)
+    return blob, g_starts, g_nbytes

@@ -1,0 +1,387 @@
+"""Binding layer: the names the reference's Cython module exports, on top of the HIP C ABI.
+
+Mirrors src/flacarray/libflacarray/libflacarray.pyx of the reference: `encode_flac` (:529),
+`decode_flac` (:713), `wrap_encode_i32[_threaded]` (:285/:346), `wrap_decode_i32` (:597),
+`wrap_float32_to_int32` (:113), `wrap_int32_to_float32` (:215) -- same arguments, return
+shapes/dtypes and error text.  numpy in / numpy out goes through the host-pointer C entry
+points; the `*_device` functions at the bottom take torch tensors already resident in HBM.
+
+The int64 / float64 twins (2-channel streams) are outside this hot path and raise
+NotImplementedError.
+"""
+import ctypes
+import weakref
+
+import numpy as np
+
+from . import _lib
+
+flac_i32_dtype = np.dtype(np.int32)
+flac_i64_dtype = np.dtype(np.int64)
+compressed_dtype = np.dtype(np.uint8)
+offset_dtype = np.dtype(np.int64)
+
+_NOT_I64 = "the int64/float64 (2-channel) path is not part of the MI355X hot path"
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def _adopt_malloc(addr, n):
+    """numpy view of a malloc()'d buffer that free()s it when the last view dies."""
+    if n == 0:
+        _lib.libc_free(addr)
+        return np.zeros(0, dtype=np.uint8)
+    buf = (ctypes.c_uint8 * n).from_address(addr)
+    arr = np.frombuffer(buf, dtype=np.uint8)
+    weakref.finalize(buf, _lib.libc_free, addr)
+    return arr
+
+
+def wrap_float32_to_int32(flatdata, n_stream, stream_size, quanta):
+    """libflacarray.pyx:113-161.  `quanta` is used only if len(quanta) == n_stream."""
+    _lib.require_device()
+    flatdata = np.ascontiguousarray(flatdata, dtype=np.float32)
+    size = n_stream * stream_size
+    output = np.empty(size, dtype=np.int32)
+    offsets = np.empty(n_stream, dtype=np.float32)
+    gains = np.empty(n_stream, dtype=np.float32)
+    q = None
+    if len(quanta) == n_stream:
+        q = np.ascontiguousarray(quanta, dtype=np.float32)
+    errcode = _lib.lib().float32_to_int32(
+        _ptr(flatdata), n_stream, stream_size, _ptr(q) if q is not None else None, _ptr(output), _ptr(offsets), _ptr(gains)
+    )
+    if errcode & _lib.ERROR_NAN_INPUT:
+        raise RuntimeError("Cannot convert data with NaNs to integers")
+    if errcode != 0:
+        raise RuntimeError(f"Encoding failed, return code = {errcode}")
+    return (output, offsets, gains)
+
+
+def wrap_int32_to_float32(idata, n_stream, stream_size, offsets, gains):
+    """libflacarray.pyx:215-247"""
+    _lib.require_device()
+    idata = np.ascontiguousarray(idata, dtype=np.int32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.float32)
+    gains = np.ascontiguousarray(gains, dtype=np.float32)
+    output = np.empty(n_stream * stream_size, dtype=np.float32)
+    _lib.lib().int32_to_float32(_ptr(idata), n_stream, stream_size, _ptr(offsets), _ptr(gains), _ptr(output))
+    return output
+
+
+def _wrap_encode(fn, flatdata, n_stream, stream_size, level):
+    _lib.require_device()
+    flatdata = np.ascontiguousarray(flatdata, dtype=np.int32)
+    flat_starts = np.empty(n_stream, dtype=np.int64)
+    flat_nbytes = np.empty(n_stream, dtype=np.int64)
+    n_bytes = ctypes.c_int64(0)
+    raw = ctypes.c_void_p(None)
+    errcode = fn(_ptr(flatdata), n_stream, stream_size, level, ctypes.byref(n_bytes), _ptr(flat_starts), ctypes.byref(raw))
+    if errcode != 0:
+        raise RuntimeError(f"Encoding failed, return code = {errcode}")
+    flat_nbytes[:-1] = np.diff(flat_starts)
+    flat_nbytes[-1] = n_bytes.value - flat_starts[-1]
+    return (_adopt_malloc(raw.value, n_bytes.value), flat_starts, flat_nbytes)
+
+
+def wrap_encode_i32(flatdata, n_stream, stream_size, level):
+    """libflacarray.pyx:285-343"""
+    return _wrap_encode(_lib.lib().encode_i32, flatdata, n_stream, stream_size, level)
+
+
+def wrap_encode_i32_threaded(flatdata, n_stream, stream_size, level):
+    """libflacarray.pyx:346-404"""
+    return _wrap_encode(_lib.lib().encode_i32_threaded, flatdata, n_stream, stream_size, level)
+
+
+def wrap_decode_i32(compressed, starts, nbytes, n_stream, stream_size, first_sample, last_sample, use_threads):
+    """libflacarray.pyx:597-653"""
+    _lib.require_device()
+    n_decode = stream_size
+    if first_sample >= 0 and last_sample >= 0:
+        n_decode = last_sample - first_sample
+    compressed = np.ascontiguousarray(compressed, dtype=np.uint8)
+    starts = np.ascontiguousarray(starts, dtype=np.int64)
+    nbytes = np.ascontiguousarray(nbytes, dtype=np.int64)
+    output = np.empty(max(n_stream * n_decode, 0), dtype=flac_i32_dtype)
+    errcode = _lib.lib().decode_i32(
+        _ptr(compressed), _ptr(starts), _ptr(nbytes), n_stream, stream_size, first_sample, last_sample, _ptr(output),
+        bool(use_threads),
+    )
+    if errcode != 0:
+        raise RuntimeError(f"Decoding failed, return code = {errcode}")
+    return output
+
+
+def _no_i64(*args, **kwargs):
+    raise NotImplementedError(_NOT_I64)
+
+
+wrap_encode_i64 = wrap_encode_i64_threaded = wrap_decode_i64 = _no_i64
+wrap_float64_to_int64 = wrap_int64_to_float64 = _no_i64
+
+
+def encode_flac(data, level, use_threads=False):
+    """Compress an integer array to FLAC streams (libflacarray.pyx:529-594).
+
+    Returns (compressed bytestream, stream starting bytes, stream nbytes); starts and nbytes
+    have the leading shape of `data` and are at least 1-D.
+    """
+    if data.dtype != flac_i32_dtype and data.dtype != flac_i64_dtype:
+        raise RuntimeError("Only 32bit or 64bit integer data is supported")
+    if not data.flags.c_contiguous:
+        raise RuntimeError("Only C-contiguous arrays are supported")
+    if level < 0 or level > 8:
+        raise RuntimeError("FLAC only supports compression levels 0-8")
+    if data.dtype == flac_i64_dtype:
+        raise NotImplementedError(_NOT_I64)
+    stream_size = data.shape[-1]
+    if len(data.shape[:-1]) == 0:
+        n_stream = 1
+        starts_shape = (1,)
+    else:
+        n_stream = int(np.prod(data.shape[:-1]))
+        starts_shape = data.shape[:-1]
+    flatdata = data.reshape((-1,))
+    if use_threads:
+        compressed, flatstarts, flatnbytes = wrap_encode_i32_threaded(flatdata, n_stream, stream_size, level)
+    else:
+        compressed, flatstarts, flatnbytes = wrap_encode_i32(flatdata, n_stream, stream_size, level)
+    return (compressed, flatstarts.reshape(starts_shape), flatnbytes.reshape(starts_shape))
+
+
+def decode_flac(compressed, starts, nbytes, stream_size, first_sample=-1, last_sample=-1, use_threads=False, is_int64=False):
+    """Decompress FLAC streams (libflacarray.pyx:713-823); output shape starts.shape + (n_decode,)."""
+    if compressed.dtype != compressed_dtype:
+        raise RuntimeError("Compressed data should be of type uint8")
+    if not compressed.flags.c_contiguous:
+        raise RuntimeError("Only C-contiguous arrays are supported")
+    if starts.dtype != offset_dtype:
+        raise RuntimeError("starts data should be of type int64")
+    if not starts.flags.c_contiguous:
+        raise RuntimeError("Only C-contiguous arrays are supported")
+    if nbytes.dtype != offset_dtype:
+        raise RuntimeError("nbytes data should be of type int64")
+    if not nbytes.flags.c_contiguous:
+        raise RuntimeError("Only C-contiguous arrays are supported")
+    if stream_size <= 0:
+        raise RuntimeError("You must specify the non-zero output stream size")
+    if len(compressed.shape) != 1:
+        raise RuntimeError("Compressed byte array should be one dimensional")
+    n_decode = stream_size
+    if first_sample >= 0 and last_sample >= 0:
+        if last_sample > stream_size:
+            raise RuntimeError("last_sample is beyond end of stream")
+        if first_sample > stream_size - 1:
+            raise RuntimeError("first_sample is beyond last element of stream")
+        if first_sample >= last_sample:
+            raise RuntimeError("first_sample is larger than last_sample")
+        n_decode = last_sample - first_sample
+    if is_int64:
+        raise NotImplementedError(_NOT_I64)
+    output_shape = starts.shape + (n_decode,)
+    n_stream = int(np.prod(starts.shape))
+    flat_output = wrap_decode_i32(
+        compressed, starts.reshape((-1,)), nbytes.reshape((-1,)), n_stream, int(stream_size), int(first_sample),
+        int(last_sample), use_threads,
+    )
+    return flat_output.reshape(output_shape)
+
+
+# ---------------------------------------------------------------------------------------------
+# Device-resident variants (torch tensors on the GPU; torch supplies memory and streams only)
+# ---------------------------------------------------------------------------------------------
+def _torch():
+    import torch
+
+    return torch
+
+
+def _stream_ptr():
+    torch = _torch()
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dp(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class EncodeWorkspace:
+    """Reusable HBM scratch for encode_flac_device (per-frame slots + scan arrays)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        torch = _torch()
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = None
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self.buf
+
+
+def encode_flac_device(data, level=5, workspace=None, return_info=False):
+    """Encode a C-contiguous int32 CUDA tensor [..., stream_size] held in HBM.
+
+    Returns (compressed uint8 tensor, starts int64 tensor, nbytes int64 tensor), all on the
+    device, starts/nbytes with the leading shape of `data` (at least 1-D) -- the device-resident
+    analogue of encode_flac (libflacarray.pyx:529-594).
+    """
+    torch = _torch()
+    if data.dtype != torch.int32:
+        raise RuntimeError("Only 32bit or 64bit integer data is supported")
+    if not data.is_contiguous():
+        raise RuntimeError("Only C-contiguous arrays are supported")
+    if level < 0 or level > 8:
+        raise RuntimeError("FLAC only supports compression levels 0-8")
+    if not data.is_cuda:
+        raise RuntimeError("encode_flac_device needs a tensor on the GPU")
+    stream_size = data.shape[-1]
+    if data.dim() == 1:
+        n_stream, starts_shape = 1, (1,)
+    else:
+        n_stream = int(np.prod(data.shape[:-1]))
+        starts_shape = tuple(data.shape[:-1])
+    L = _lib.lib()
+    ws_bytes = L.fa_encode_workspace_bytes(n_stream, stream_size, level)
+    if ws_bytes < 0:
+        raise RuntimeError("Encoding failed, return code = 512")
+    if workspace is None:
+        workspace = EncodeWorkspace()
+    ws = workspace.get(ws_bytes, data.device)
+    starts = torch.empty(n_stream, dtype=torch.int64, device=data.device)
+    nbytes = torch.empty(n_stream, dtype=torch.int64, device=data.device)
+    info = None
+    if return_info:
+        bs = 1152 if level <= 2 else 4096
+        nf = (stream_size + bs - 1) // bs
+        info = torch.zeros((n_stream * nf, 8), dtype=torch.int32, device=data.device)
+    total = ctypes.c_int64(0)
+    with torch.cuda.device(data.device):
+        errcode = L.fa_encode_i32_device_begin(
+            _dp(data), n_stream, stream_size, level, _dp(ws), ws.numel(), _dp(starts), _dp(nbytes), ctypes.byref(total),
+            _dp(info), _stream_ptr(),
+        )
+        if errcode != 0:
+            raise RuntimeError(f"Encoding failed, return code = {errcode}")
+        compressed = torch.empty(total.value, dtype=torch.uint8, device=data.device)
+        errcode = L.fa_encode_i32_device_finish(n_stream, stream_size, level, _dp(ws), _dp(starts), _dp(compressed), _stream_ptr())
+        if errcode != 0:
+            raise RuntimeError(f"Encoding failed, return code = {errcode}")
+    out = (compressed, starts.reshape(starts_shape), nbytes.reshape(starts_shape))
+    if return_info:
+        return out + (info,)
+    return out
+
+
+def decode_flac_device(compressed, starts, nbytes, stream_size, first_sample=-1, last_sample=-1, offsets=None, gains=None):
+    """Decode device-resident streams into an int32 tensor (or float32 when offsets/gains are
+    given: the int->float restore of utils.c:350-368 is fused into the store)."""
+    torch = _torch()
+    if compressed.dtype != torch.uint8:
+        raise RuntimeError("Compressed data should be of type uint8")
+    if starts.dtype != torch.int64:
+        raise RuntimeError("starts data should be of type int64")
+    if nbytes.dtype != torch.int64:
+        raise RuntimeError("nbytes data should be of type int64")
+    if not (compressed.is_contiguous() and starts.is_contiguous() and nbytes.is_contiguous()):
+        raise RuntimeError("Only C-contiguous arrays are supported")
+    if stream_size <= 0:
+        raise RuntimeError("You must specify the non-zero output stream size")
+    n_decode = stream_size
+    if first_sample >= 0 and last_sample >= 0:
+        if last_sample > stream_size:
+            raise RuntimeError("last_sample is beyond end of stream")
+        if first_sample > stream_size - 1:
+            raise RuntimeError("first_sample is beyond last element of stream")
+        if first_sample >= last_sample:
+            raise RuntimeError("first_sample is larger than last_sample")
+        n_decode = last_sample - first_sample
+    if (offsets is None) != (gains is None):
+        raise RuntimeError("When specifying offsets, you must also provide the gains")
+    n_stream = int(np.prod(starts.shape))
+    shape = tuple(starts.shape) + (n_decode,)
+    dev = compressed.device
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        if offsets is None:
+            out = torch.empty(shape, dtype=torch.int32, device=dev)
+            errcode = L.fa_decode_i32_device(
+                _dp(compressed), compressed.numel(), _dp(starts), _dp(nbytes), n_stream, stream_size, first_sample, last_sample,
+                _dp(out), None, None, None, _stream_ptr(),
+            )
+        else:
+            out = torch.empty(shape, dtype=torch.float32, device=dev)
+            offsets = offsets.to(device=dev, dtype=torch.float32).contiguous()
+            gains = gains.to(device=dev, dtype=torch.float32).contiguous()
+            errcode = L.fa_decode_i32_device(
+                _dp(compressed), compressed.numel(), _dp(starts), _dp(nbytes), n_stream, stream_size, first_sample, last_sample,
+                None, _dp(out), _dp(offsets), _dp(gains), _stream_ptr(),
+            )
+    if errcode != 0:
+        raise RuntimeError(f"Decoding failed, return code = {errcode}")
+    return out
+
+
+def decode_slices_device(compressed, starts, nbytes, stream_size, slice_stream, slice_first, slice_count, offsets=None, gains=None):
+    """Batched random access: slice i = samples [first[i], first[i]+count[i]) of (flat) stream
+    slice_stream[i].  Returns (flat output tensor, int64 numpy array of output offsets).  The
+    reference needs one decode call per slice (decompress.py:42-48)."""
+    torch = _torch()
+    slice_stream = np.ascontiguousarray(slice_stream, dtype=np.int64)
+    slice_first = np.ascontiguousarray(slice_first, dtype=np.int64)
+    slice_count = np.ascontiguousarray(slice_count, dtype=np.int64)
+    n = slice_stream.shape[0]
+    out_off = np.zeros(n, dtype=np.int64)
+    if n > 1:
+        np.cumsum(slice_count[:-1], out=out_off[1:])
+    total = int(slice_count.sum())
+    dev = compressed.device
+    n_stream = int(np.prod(starts.shape))
+    L = _lib.lib()
+    f32 = offsets is not None
+    out = torch.empty(total, dtype=torch.float32 if f32 else torch.int32, device=dev)
+    if f32:
+        # per-task gains/offsets are looked up per slice on the host side
+        soff = offsets.reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
+        sgain = gains.reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
+    with torch.cuda.device(dev):
+        errcode = L.fa_decode_slices_i32_device(
+            _dp(compressed), compressed.numel(), _dp(starts), _dp(nbytes), n_stream, stream_size, n,
+            ctypes.c_void_p(slice_stream.ctypes.data), ctypes.c_void_p(slice_first.ctypes.data),
+            ctypes.c_void_p(slice_count.ctypes.data), ctypes.c_void_p(out_off.ctypes.data),
+            None if f32 else _dp(out), _dp(out) if f32 else None, _dp(soff) if f32 else None, _dp(sgain) if f32 else None,
+            _stream_ptr(),
+        )
+    if errcode != 0:
+        raise RuntimeError(f"Decoding failed, return code = {errcode}")
+    return out, out_off
+
+
+def float32_to_int32_device(data, quanta=None):
+    """Device float32 -> int32 quantisation (utils.c:160-243); returns (int32 tensor, offsets, gains)."""
+    torch = _torch()
+    if data.dtype != torch.float32 or not data.is_contiguous():
+        raise ValueError("Only float32 and float64 data are supported")
+    stream_size = data.shape[-1]
+    lead = tuple(data.shape[:-1]) if data.dim() > 1 else (1,)
+    n_stream = int(np.prod(lead))
+    out = torch.empty(data.shape, dtype=torch.int32, device=data.device)
+    offsets = torch.empty(n_stream, dtype=torch.float32, device=data.device)
+    gains = torch.empty(n_stream, dtype=torch.float32, device=data.device)
+    q = None
+    if quanta is not None:
+        q = quanta.to(device=data.device, dtype=torch.float32).reshape(-1).contiguous()
+        if q.numel() != n_stream:
+            raise RuntimeError("quanta must have one entry per stream")
+    with torch.cuda.device(data.device):
+        errcode = _lib.lib().fa_float32_to_int32_device(
+            _dp(data), n_stream, stream_size, _dp(q), _dp(out), _dp(offsets), _dp(gains), _stream_ptr()
+        )
+    if errcode & _lib.ERROR_NAN_INPUT:
+        raise RuntimeError("Cannot convert data with NaNs to integers")
+    if errcode != 0:
+        raise RuntimeError(f"Encoding failed, return code = {errcode}")
+    return out, offsets.reshape(lead), gains.reshape(lead)

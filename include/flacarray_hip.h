@@ -1,0 +1,129 @@
+/*
+ * flacarray_hip.h -- C ABI of the MI355X-native FLAC encode/decode path.
+ *
+ * The first group of entry points has exactly the names, argument lists, return codes and
+ * ownership rules of the reference's C layer, so the reference's Cython binding
+ * (src/flacarray/libflacarray/libflacarray.pyx:18-110 `cdef extern from "flacarray.h"`) can be
+ * linked against libflacarray_hip.so instead of compress.c/decompress.c/utils.c + libFLAC.
+ * The second group takes DEVICE pointers (data already resident in HBM) and is what the
+ * Python layer, the tests and bench.py use.
+ *
+ * No torch / HIP types appear in any signature: `void* stream` is a hipStream_t passed as an
+ * opaque pointer (NULL = default stream).
+ */
+#ifndef FLACARRAY_HIP_H
+#define FLACARRAY_HIP_H
+
+#include <stdbool.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Error bit-codes, identical to the reference (src/flacarray/libflacarray/flacarray.h:20-40). */
+#define FA_ERROR_NONE 0
+#define FA_ERROR_ALLOC (1 << 0)
+#define FA_ERROR_INVALID_LEVEL (1 << 1)
+#define FA_ERROR_ZERO_NSTREAM (1 << 2)
+#define FA_ERROR_ZERO_STREAMSIZE (1 << 3)
+#define FA_ERROR_ENCODE_INIT (1 << 8)
+#define FA_ERROR_ENCODE_PROCESS (1 << 9)
+#define FA_ERROR_DECODE_INIT (1 << 13)
+#define FA_ERROR_DECODE_PROCESS (1 << 14)
+#define FA_ERROR_DECODE_STREAMSIZE (1 << 16)
+#define FA_ERROR_DECODE_SAMPLE_RANGE (1 << 17)
+#define FA_ERROR_DECODE_SEEK (1 << 18)
+#define FA_ERROR_CONVERT_TYPE (1 << 19)
+/* additions of this library */
+#define FA_ERROR_DEVICE (1 << 24)   /* a HIP runtime call failed (no GPU, out of memory, ...) */
+#define FA_ERROR_NAN_INPUT (1 << 25) /* float32_to_int32 saw a NaN */
+
+/* ---------------------------------------------------------------------------------------
+ * Group 1: host-pointer drop-ins for the reference C ABI
+ * ------------------------------------------------------------------------------------- */
+
+/* replaces encode_i32, flacarray.h:209-217 (compress.c:440).  `*bytes` is malloc()'d by the
+ * callee and owned by the caller (free()), as in compress.c:251,414. */
+int encode_i32(int32_t* const data, int64_t n_stream, int64_t stream_size, uint32_t level, int64_t* n_bytes,
+               int64_t* starts, unsigned char** bytes);
+
+/* replaces encode_i32_threaded, flacarray.h:219-227 (compress.c:461); same work on the GPU */
+int encode_i32_threaded(int32_t* const data, int64_t n_stream, int64_t stream_size, uint32_t level, int64_t* n_bytes,
+                        int64_t* starts, unsigned char** bytes);
+
+/* replaces decode_i32, flacarray.h:249-259 (decompress.c:318).  first_sample/last_sample < 0
+ * decodes whole streams; otherwise the half-open range [first_sample, last_sample) of every
+ * stream, row stride last_sample-first_sample (decompress.c:209-222,254). */
+int decode_i32(unsigned char* const bytes, int64_t* const starts, int64_t* const nbytes, int64_t n_stream,
+               int64_t stream_size, int64_t first_sample, int64_t last_sample, int32_t* data, bool use_threads);
+
+/* replaces float32_to_int32, flacarray.h:275-283 (utils.c:160); quanta == NULL: per-stream
+ * quanta from the data range */
+int float32_to_int32(float const* input, int64_t n_stream, int64_t stream_size, float const* quanta, int32_t* output,
+                     float* offsets, float* gains);
+
+/* replaces int32_to_float32, flacarray.h:304-311 (utils.c:350) */
+void int32_to_float32(int32_t const* input, int64_t n_stream, int64_t stream_size, float const* offsets,
+                      float const* gains, float* output);
+
+/* ---------------------------------------------------------------------------------------
+ * Group 2: device-pointer entry points (every pointer named d_* is HBM memory)
+ * ------------------------------------------------------------------------------------- */
+
+/* bytes of scratch fa_encode_i32_device_begin needs for this problem size */
+int64_t fa_encode_workspace_bytes(int64_t n_stream, int64_t stream_size, uint32_t level);
+
+/* Encode, phase 1: analyse and bit-pack every frame into the workspace, size the output.
+ * Writes d_starts[n_stream], d_nbytes[n_stream] (device) and *h_total_bytes (host; the call
+ * synchronises the stream to deliver it).  d_info may be NULL; otherwise it receives 8 int32
+ * per frame {type, order, partition order, wasted bits, shift, precision, bytes, blocksize}. */
+int fa_encode_i32_device_begin(const int32_t* d_data, int64_t n_stream, int64_t stream_size, uint32_t level,
+                               void* d_workspace, int64_t workspace_bytes, int64_t* d_starts, int64_t* d_nbytes,
+                               int64_t* h_total_bytes, int32_t* d_info, void* stream);
+
+/* Encode, phase 2: assemble the blob (stream headers, byte-exact concatenation, CRC-16) into
+ * d_bytes[*h_total_bytes].  Same arguments as phase 1. */
+int fa_encode_i32_device_finish(int64_t n_stream, int64_t stream_size, uint32_t level, void* d_workspace,
+                                const int64_t* d_starts, unsigned char* d_bytes, void* stream);
+
+/* Decode [first_sample,last_sample) (or everything when either is negative) of n_stream
+ * streams.  Exactly one of d_out_i32 / d_out_f32 is non-NULL; with d_out_f32 the int32 ->
+ * float32 restore (utils.c:350-368) is fused into the store and d_offsets/d_gains[n_stream]
+ * are required.  Returns the OR of the error bits (synchronises the stream). */
+int fa_decode_i32_device(const unsigned char* d_bytes, int64_t n_bytes, const int64_t* d_starts,
+                         const int64_t* d_nbytes, int64_t n_stream, int64_t stream_size, int64_t first_sample,
+                         int64_t last_sample, int32_t* d_out_i32, float* d_out_f32, const float* d_offsets,
+                         const float* d_gains, void* stream);
+
+/* Batched random access: slice i is samples [first[i], first[i]+count[i]) of stream
+ * slice_stream[i]; its samples are written at element offset out_offset[i] of the output.
+ * The four slice arrays are HOST arrays of length n_slices.  The reference needs one
+ * decode_i32 call per slice for this (decompress.py:42-48: one range for all streams). */
+int fa_decode_slices_i32_device(const unsigned char* d_bytes, int64_t n_bytes, const int64_t* d_starts,
+                                const int64_t* d_nbytes, int64_t n_stream, int64_t stream_size, int64_t n_slices,
+                                const int64_t* slice_stream, const int64_t* slice_first, const int64_t* slice_count,
+                                const int64_t* out_offset, int32_t* d_out_i32, float* d_out_f32,
+                                const float* d_offsets, const float* d_gains, void* stream);
+
+/* float32 -> int32 quantisation on device; d_quanta may be NULL.  Returns FA_ERROR_NAN_INPUT
+ * if any input is NaN (outputs are then unspecified). */
+int fa_float32_to_int32_device(const float* d_input, int64_t n_stream, int64_t stream_size, const float* d_quanta,
+                               int32_t* d_output, float* d_offsets, float* d_gains, void* stream);
+
+int fa_int32_to_float32_device(const int32_t* d_input, int64_t n_stream, int64_t stream_size, const float* d_offsets,
+                               const float* d_gains, float* d_output, void* stream);
+
+/* free the library's cached device scratch (decode tables, staging buffers) */
+void fa_release_scratch(void);
+
+/* number of visible HIP devices (0 when there is no GPU); never initialises a context */
+int fa_device_count(void);
+
+/* library version string */
+const char* fa_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLACARRAY_HIP_H */

@@ -1,0 +1,156 @@
+"""ctypes loader for the CPU oracle (oracle/flac_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the cpu_baseline leg
+of bench.py.  Nothing under flacarray_amd/ may import this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class FrameInfo(ctypes.Structure):
+    _fields_ = [
+        ("type", ctypes.c_int32),
+        ("order", ctypes.c_int32),
+        ("porder", ctypes.c_int32),
+        ("wasted", ctypes.c_int32),
+        ("shift", ctypes.c_int32),
+        ("precision", ctypes.c_int32),
+        ("nbytes", ctypes.c_int32),
+        ("blocksize", ctypes.c_int32),
+    ]
+
+
+def build():
+    """Compile liboracle.so with gcc if it is missing or older than its source."""
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "flac_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = ctypes.CDLL(build())
+        i64, i32p, u8p = ctypes.c_int64, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint8)
+        i64p, f32p = ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_float)
+        L.oracle_encode_i32.argtypes = [i32p, i64, i64, ctypes.c_uint32, i64p, i64p, ctypes.POINTER(u8p), ctypes.c_int]
+        L.oracle_encode_i32.restype = ctypes.c_int
+        L.oracle_decode_i32.argtypes = [u8p, i64p, i64p, i64, i64, i64, i64, i32p, ctypes.c_int]
+        L.oracle_decode_i32.restype = ctypes.c_int
+        L.oracle_float32_to_int32.argtypes = [f32p, i64, i64, f32p, i32p, f32p, f32p]
+        L.oracle_float32_to_int32.restype = ctypes.c_int
+        L.oracle_int32_to_float32.argtypes = [i32p, i64, i64, f32p, f32p, f32p]
+        L.oracle_int32_to_float32.restype = None
+        L.oracle_encode_stream_info.argtypes = [i32p, i64, ctypes.c_uint32, ctypes.POINTER(FrameInfo)]
+        L.oracle_encode_stream_info.restype = ctypes.c_int
+        L.oracle_free.argtypes = [ctypes.c_void_p]
+        L.oracle_tukey_window.argtypes = [ctypes.c_int, f32p]
+        L.oracle_det_log2.argtypes = [ctypes.c_double]
+        L.oracle_det_log2.restype = ctypes.c_double
+        L.oracle_num_threads.restype = ctypes.c_int
+        _LIB = L
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+def encode_i32(data, level=5, use_threads=False):
+    """(blob uint8, starts int64[n_stream], nbytes int64[n_stream]) for a 2-D C-contiguous int32 array."""
+    data = np.ascontiguousarray(data, dtype=np.int32)
+    if data.ndim == 1:
+        data = data.reshape(1, -1)
+    n_stream, stream_size = data.shape
+    starts = np.zeros(n_stream, dtype=np.int64)
+    n_bytes = ctypes.c_int64(0)
+    raw = ctypes.POINTER(ctypes.c_uint8)()
+    err = lib().oracle_encode_i32(
+        _p(data, ctypes.c_int32), n_stream, stream_size, level, ctypes.byref(n_bytes), _p(starts, ctypes.c_int64),
+        ctypes.byref(raw), int(use_threads),
+    )
+    if err != 0:
+        raise RuntimeError(f"Encoding failed, return code = {err}")
+    blob = np.ctypeslib.as_array(raw, shape=(n_bytes.value,)).copy()
+    lib().oracle_free(raw)
+    nbytes = np.empty(n_stream, dtype=np.int64)
+    nbytes[:-1] = np.diff(starts)
+    nbytes[-1] = n_bytes.value - starts[-1]
+    return blob, starts, nbytes
+
+
+def decode_i32(blob, starts, nbytes, stream_size, first=-1, last=-1, use_threads=False):
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    starts = np.ascontiguousarray(starts, dtype=np.int64).reshape(-1)
+    nbytes = np.ascontiguousarray(nbytes, dtype=np.int64).reshape(-1)
+    n_stream = starts.shape[0]
+    n_decode = stream_size if (first < 0 or last < 0) else last - first
+    out = np.empty((n_stream, max(n_decode, 0)), dtype=np.int32)
+    err = lib().oracle_decode_i32(
+        _p(blob, ctypes.c_uint8), _p(starts, ctypes.c_int64), _p(nbytes, ctypes.c_int64), n_stream, stream_size,
+        first, last, _p(out, ctypes.c_int32), int(use_threads),
+    )
+    if err != 0:
+        raise RuntimeError(f"Decoding failed, return code = {err}")
+    return out
+
+
+def float32_to_int32(data, quanta=None):
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    if data.ndim == 1:
+        data = data.reshape(1, -1)
+    n_stream, stream_size = data.shape
+    out = np.empty_like(data, dtype=np.int32)
+    offsets = np.empty(n_stream, dtype=np.float32)
+    gains = np.empty(n_stream, dtype=np.float32)
+    qp = None
+    if quanta is not None:
+        quanta = np.ascontiguousarray(quanta, dtype=np.float32).reshape(-1)
+        assert quanta.shape[0] == n_stream
+        qp = _p(quanta, ctypes.c_float)
+    lib().oracle_float32_to_int32(
+        _p(data, ctypes.c_float), n_stream, stream_size, qp, _p(out, ctypes.c_int32), _p(offsets, ctypes.c_float),
+        _p(gains, ctypes.c_float),
+    )
+    return out, offsets, gains
+
+
+def int32_to_float32(idata, offsets, gains):
+    idata = np.ascontiguousarray(idata, dtype=np.int32)
+    if idata.ndim == 1:
+        idata = idata.reshape(1, -1)
+    n_stream, stream_size = idata.shape
+    offsets = np.ascontiguousarray(offsets, dtype=np.float32).reshape(-1)
+    gains = np.ascontiguousarray(gains, dtype=np.float32).reshape(-1)
+    out = np.empty(idata.shape, dtype=np.float32)
+    lib().oracle_int32_to_float32(
+        _p(idata, ctypes.c_int32), n_stream, stream_size, _p(offsets, ctypes.c_float), _p(gains, ctypes.c_float),
+        _p(out, ctypes.c_float),
+    )
+    return out
+
+
+def stream_info(x, level=5):
+    """Per-frame encoder decisions for one 1-D int32 stream (list of dicts)."""
+    x = np.ascontiguousarray(x, dtype=np.int32).reshape(-1)
+    bs = 1152 if level <= 2 else 4096
+    nf = (x.shape[0] + bs - 1) // bs
+    infos = (FrameInfo * nf)()
+    err = lib().oracle_encode_stream_info(_p(x, ctypes.c_int32), x.shape[0], level, infos)
+    if err != 0:
+        raise RuntimeError(f"Encoding failed, return code = {err}")
+    return [{k: getattr(i, k) for k, _ in FrameInfo._fields_} for i in infos]
+
+
+def tukey_window(n):
+    w = np.empty(n, dtype=np.float32)
+    lib().oracle_tukey_window(n, _p(w, ctypes.c_float))
+    return w

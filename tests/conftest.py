@@ -1,0 +1,56 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def sinusoid_noise_i32(n_ch, n_samp, seed=123456789, amp=2**16):
+    """S2 of SURVEY.md 8(d): int version of the reference generator (src/flacarray/demo.py:75-97):
+    rint(A*(dc_c + s_c*(2 sin(2pi 3f t) + 6 sin(2pi f t)) + N(0,1))), f = 5/T."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n_samp)
+    f = 5.0 / n_samp
+    dc = 5.0 * (rng.random((n_ch, 1)) - 0.5)
+    wave = 2.0 * np.sin(2 * np.pi * 3 * f * t) + 6.0 * np.sin(2 * np.pi * f * t)
+    scale = rng.random((n_ch, 1))
+    x = dc + scale * wave + rng.normal(0.0, 1.0, (n_ch, n_samp))
+    return np.rint(amp * x).astype(np.int32)
+
+
+def sinusoid_noise_f32(n_ch, n_samp, seed=123456789):
+    """S3: the same field before rint, float32, amplitude 1."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n_samp)
+    f = 5.0 / n_samp
+    dc = 5.0 * (rng.random((n_ch, 1)) - 0.5)
+    wave = 2.0 * np.sin(2 * np.pi * 3 * f * t) + 6.0 * np.sin(2 * np.pi * f * t)
+    scale = rng.random((n_ch, 1))
+    return (dc + scale * wave + rng.normal(0.0, 1.0, (n_ch, n_samp))).astype(np.float32)
+
+
+def full_range_i32(shape, seed=123456789):
+    """Uniform full-range int32 with INT32_MIN / INT32_MAX at flat positions 0 / 1
+    (reference recipe: src/flacarray/demo.py:58-68, tests/bindings.py:34-39)."""
+    rng = np.random.default_rng(seed)
+    flat = rng.integers(-(2**31), 2**31 - 1, size=int(np.prod(shape)), dtype=np.int64).astype(np.int32)
+    flat[0] = -(2**31)
+    if flat.size > 1:
+        flat[1] = 2**31 - 1
+    return flat.reshape(shape)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+
+    O.lib()
+    return O

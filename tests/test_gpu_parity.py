@@ -1,0 +1,164 @@
+"""GPU parity: the HIP path against the CPU oracle on the same seeded inputs (bit-exact)."""
+import numpy as np
+import pytest
+
+from conftest import full_range_i32, sinusoid_noise_f32, sinusoid_noise_i32
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fa():
+    import flacarray_amd
+
+    return flacarray_amd
+
+
+def _frame_diff(oracle, x, level, info_gpu, nf):
+    """Describe the first frame whose decisions differ (for assertion messages)."""
+    msgs = []
+    keys = ["type", "order", "porder", "wasted", "shift", "precision", "nbytes", "blocksize"]
+    for s in range(x.shape[0]):
+        oi = oracle.stream_info(x[s], level)
+        for f in range(nf):
+            g = info_gpu[s * nf + f]
+            o = [oi[f][k] for k in keys]
+            if list(g) != o:
+                msgs.append(f"stream {s} frame {f}: gpu {dict(zip(keys, g))} oracle {dict(zip(keys, o))}")
+                if len(msgs) >= 5:
+                    return "\n".join(msgs)
+    return "\n".join(msgs)
+
+
+def _encode_device(fa, x, level):
+    import torch
+
+    d = torch.from_numpy(x).cuda()
+    comp, st, nb, info = fa.encode_flac_device(d, level=level, return_info=True)
+    torch.cuda.synchronize()
+    return comp.cpu().numpy(), st.cpu().numpy(), nb.cpu().numpy(), info.cpu().numpy()
+
+
+CASES = [
+    ("sinus16x65536", lambda: sinusoid_noise_i32(16, 65536)),
+    ("sinus3x10000", lambda: sinusoid_noise_i32(3, 10000, seed=7)),
+    ("fullrange3x10000", lambda: full_range_i32((3, 10000))),
+    ("small_amp", lambda: sinusoid_noise_i32(4, 12288, seed=11, amp=8)),
+    ("wasted_bits", lambda: (sinusoid_noise_i32(4, 9000, seed=5, amp=64) * 16).astype(np.int32)),
+    ("zeros", lambda: np.zeros((2, 5000), dtype=np.int32)),
+    ("const", lambda: np.full((2, 4097), -77777, dtype=np.int32)),
+    ("ramp", lambda: (np.arange(3 * 8192, dtype=np.int64).reshape(3, 8192) * 3 - 999).astype(np.int32)),
+    ("spikes", lambda: _spikes()),
+]
+
+
+def _spikes():
+    rng = np.random.default_rng(99)
+    x = rng.integers(-3, 4, size=(4, 8192)).astype(np.int32)
+    x[0, 100] = 2**31 - 1
+    x[1, 5000] = -(2**31)
+    x[2, ::512] = 2**28
+    return x
+
+
+@pytest.mark.parametrize("name,gen", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("level", [0, 3, 5, 8])
+def test_encode_bytes_match_oracle(fa, oracle, name, gen, level):
+    x = np.ascontiguousarray(gen())
+    blob_o, st_o, nb_o = oracle.encode_i32(x, level)
+    blob_g, st_g, nb_g, info = _encode_device(fa, x, level)
+    bs = 1152 if level <= 2 else 4096
+    nf = (x.shape[1] + bs - 1) // bs
+    if not (np.array_equal(nb_g.reshape(-1), nb_o) and np.array_equal(blob_g, blob_o)):
+        pytest.fail("compressed bytes differ from the oracle\n" + _frame_diff(oracle, x, level, info, nf))
+    assert np.array_equal(st_g.reshape(-1), st_o)
+
+
+@pytest.mark.parametrize("n", [1, 2, 4, 5, 15, 16, 63, 64, 65, 255, 256, 257, 1000, 4095, 4096, 4097, 10000])
+def test_encode_lengths(fa, oracle, n):
+    rng = np.random.default_rng(n)
+    x = np.stack([rng.integers(-(2**17), 2**17, n), np.cumsum(rng.integers(-50, 51, n))]).astype(np.int32)
+    for level in (2, 5):
+        blob_o, st_o, nb_o = oracle.encode_i32(x, level)
+        blob_g, st_g, nb_g, info = _encode_device(fa, x, level)
+        bs = 1152 if level <= 2 else 4096
+        nf = (n + bs - 1) // bs
+        if not np.array_equal(blob_g, blob_o):
+            pytest.fail(f"n={n} level={level}\n" + _frame_diff(oracle, x, level, info, nf))
+        assert np.array_equal(nb_g.reshape(-1), nb_o)
+
+
+def test_decode_oracle_streams(fa, oracle):
+    """Streams written by the oracle encoder decode bit-exactly on the GPU (full + slices)."""
+    import torch
+
+    for level in (0, 5, 8):
+        for x in (sinusoid_noise_i32(8, 20000, seed=3), full_range_i32((3, 10000)), _spikes()):
+            blob, st, nb = oracle.encode_i32(x, level)
+            d = fa.decode_flac_device(torch.from_numpy(blob).cuda(), torch.from_numpy(st).cuda(), torch.from_numpy(nb).cuda(), x.shape[1])
+            assert np.array_equal(d.cpu().numpy(), x)
+            n = x.shape[1]
+            for first, last in ((0, 1), (n // 2 - 5, n // 2 + 5), (4090, 8200), (n - 1, n), (1, n)):
+                d = fa.decode_flac_device(
+                    torch.from_numpy(blob).cuda(), torch.from_numpy(st).cuda(), torch.from_numpy(nb).cuda(), n, first, last
+                )
+                assert np.array_equal(d.cpu().numpy(), x[:, first:last]), (level, first, last)
+
+
+def test_host_abi_roundtrip(fa, oracle):
+    """numpy in / numpy out through the reference-shaped C ABI (encode_i32 / decode_i32)."""
+    x = sinusoid_noise_i32(12, 30000, seed=21).reshape(4, 3, 30000)
+    comp, starts, nbytes = fa.encode_flac(x, 5, use_threads=True)
+    assert starts.shape == (4, 3) and nbytes.shape == (4, 3) and comp.dtype == np.uint8
+    blob_o, st_o, nb_o = oracle.encode_i32(x.reshape(12, -1), 5)
+    assert np.array_equal(comp, blob_o) and np.array_equal(starts.reshape(-1), st_o)
+    y = fa.decode_flac(comp, starts, nbytes, 30000)
+    assert y.shape == x.shape and np.array_equal(y, x)
+    y = fa.decode_flac(comp, starts, nbytes, 30000, first_sample=14995, last_sample=15005)
+    assert np.array_equal(y, x[..., 14995:15005])
+    # oracle decodes GPU bytes
+    assert np.array_equal(oracle.decode_i32(comp, starts, nbytes, 30000), x.reshape(12, -1))
+
+
+def test_float_quantise_matches_oracle(fa, oracle):
+    import torch
+
+    x = sinusoid_noise_f32(9, 50001, seed=17)
+    x[3] = 0.0  # all-zero stream: gain 1, offset +-0
+    x[4] += 10.51
+    q = (2.0**-16 * (1 + np.arange(9) % 4)).astype(np.float32)
+    for quanta in (None, q):
+        io, offo, go = oracle.float32_to_int32(x, quanta)
+        ig, offg, gg = fa.float32_to_int32_device(torch.from_numpy(x).cuda(), None if quanta is None else torch.from_numpy(quanta))
+        assert np.array_equal(ig.cpu().numpy(), io)
+        assert np.array_equal(offg.cpu().numpy().view(np.uint32), offo.view(np.uint32))
+        assert np.array_equal(gg.cpu().numpy().view(np.uint32), go.view(np.uint32))
+        fo = oracle.int32_to_float32(io, offo, go)
+        fg = fa.int_to_float(io, offo, go)
+        assert np.array_equal(fg.view(np.uint32), fo.view(np.uint32))
+    # fused decode + dequantise == separate steps
+    io, offo, go = oracle.float32_to_int32(x, q)
+    blob, st, nb = oracle.encode_i32(io, 5)
+    d = fa.decode_flac_device(
+        torch.from_numpy(blob).cuda(), torch.from_numpy(st).cuda(), torch.from_numpy(nb).cuda(), x.shape[1],
+        offsets=torch.from_numpy(offo), gains=torch.from_numpy(go),
+    )
+    assert np.array_equal(d.cpu().numpy().view(np.uint32), oracle.int32_to_float32(io, offo, go).view(np.uint32))
+    assert np.max(np.abs(d.cpu().numpy() - x) / q[:, None]) <= 0.5 + 1e-3
+
+
+def test_scattered_slices(fa, oracle):
+    import torch
+
+    x = sinusoid_noise_i32(32, 40000, seed=4)
+    blob, st, nb = oracle.encode_i32(x, 5)
+    rng = np.random.default_rng(987654321)
+    n = 500
+    ch = rng.integers(0, 32, n)
+    cnt = rng.integers(1, 8193, n)
+    first = np.array([rng.integers(0, 40000 - c + 1) for c in cnt])
+    first[0], cnt[0] = 40000 - 1, 1
+    out, off = fa.decode_slices_device(torch.from_numpy(blob).cuda(), torch.from_numpy(st).cuda(), torch.from_numpy(nb).cuda(), 40000, ch, first, cnt)
+    out = out.cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(out[off[i] : off[i] + cnt[i]], x[ch[i], first[i] : first[i] + cnt[i]]), i
