@@ -23,6 +23,8 @@ SYMBOLS = [
     "fa_decode_slices_i32_device",
     "fa_float32_to_int32_device",
     "fa_int32_to_float32_device",
+    "fa_profile_enable",
+    "fa_profile_last",
     "fa_release_scratch",
     "fa_device_count",
     "fa_version",
@@ -46,6 +48,13 @@ def lib():
             f"{LIB_PATH} is missing: build it with `python -m flacarray_amd.build` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback."
         )
+    # If PyTorch-ROCm is present it must load ITS bundled HIP runtime first: the library then
+    # binds to the runtime already in the process (same soname) instead of bringing a second
+    # one, whose pointers and streams torch tensors would not belong to.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     i64, u32, vp, cint = ctypes.c_int64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int
     pi64 = ctypes.POINTER(ctypes.c_int64)
@@ -73,6 +82,10 @@ def lib():
     L.fa_float32_to_int32_device.restype = cint
     L.fa_int32_to_float32_device.argtypes = [vp, i64, i64, vp, vp, vp, vp]
     L.fa_int32_to_float32_device.restype = cint
+    L.fa_profile_enable.argtypes = [cint]
+    L.fa_profile_enable.restype = None
+    L.fa_profile_last.argtypes = [ctypes.POINTER(ctypes.c_float)]
+    L.fa_profile_last.restype = cint
     L.fa_release_scratch.argtypes = []
     L.fa_release_scratch.restype = None
     L.fa_device_count.argtypes = []

@@ -34,6 +34,26 @@ using namespace fa;
 
 std::mutex g_mu;
 
+// optional in-library kernel timing (HIP events on the launch stream), see fa_profile_enable
+bool g_prof = false;
+hipEvent_t g_ev[6];
+bool g_ev_ready = false;
+bool g_ev_set[3] = {false, false, false};
+
+void prof_begin(int k, hipStream_t st) {
+    if (!g_prof) return;
+    if (!g_ev_ready) {
+        for (auto& e : g_ev) (void)hipEventCreate(&e);
+        g_ev_ready = true;
+    }
+    (void)hipEventRecord(g_ev[2 * k], st);
+}
+void prof_end(int k, hipStream_t st) {
+    if (!g_prof) return;
+    (void)hipEventRecord(g_ev[2 * k + 1], st);
+    g_ev_set[k] = true;
+}
+
 struct DeviceState {
     std::map<int, float*> windows;  // blocksize -> device tukey(0.5) table
     uint16_t* crc_tab = nullptr;
@@ -249,7 +269,9 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
     }
     if (a.B > kMaxBlock * 16) return FA_ERROR_DECODE_INIT;
     const unsigned nblk = (unsigned)((a.n_tasks + 255) / 256);
+    prof_begin(2, st);
     hipLaunchKernelGGL((decode_frames_kernel<8, -1>), dim3(nblk), dim3(256), 0, st, a, d_err + 1);
+    prof_end(2, st);
     FA_HIP_TRY(hipMemcpyAsync(h_err, d_err, 16, hipMemcpyDeviceToHost, st));
     FA_HIP_TRY(hipStreamSynchronize(st));
     if (h_err[1] & kFlagNeed12) hipLaunchKernelGGL((decode_frames_kernel<12, 8>), dim3(nblk), dim3(256), 0, st, a, d_err + 1);
@@ -280,6 +302,20 @@ int validate_range(int64_t stream_size, int64_t first_sample, int64_t last_sampl
 extern "C" {
 
 const char* fa_version(void) { return "flacarray_hip 0.1.0 (gfx950)"; }
+
+void fa_profile_enable(int on) { g_prof = (on != 0); }
+
+int fa_profile_last(float* ms3) {
+    for (int k = 0; k < 3; ++k) {
+        ms3[k] = -1.0f;
+        if (g_ev_ready && g_ev_set[k]) {
+            if (hipEventSynchronize(g_ev[2 * k + 1]) != hipSuccess) return FA_ERROR_DEVICE;
+            float t = 0.0f;
+            if (hipEventElapsedTime(&t, g_ev[2 * k], g_ev[2 * k + 1]) == hipSuccess) ms3[k] = t;
+        }
+    }
+    return FA_ERROR_NONE;
+}
 
 int fa_device_count(void) {
     int n = 0;
@@ -324,12 +360,14 @@ int fa_encode_i32_device_begin(const int32_t* d_data, int64_t n_stream, int64_t 
     a.slots = reinterpret_cast<uint8_t*>(ws + pl.off_slots);
     a.frame_bytes = reinterpret_cast<uint32_t*>(ws + pl.off_fbytes);
     a.info = reinterpret_cast<FrameInfo*>(d_info);
+    prof_begin(0, st);
     switch (a.max_lpc_order) {
         case 0: launch_encode<0>(a, pl.F, st); break;
         case 6: launch_encode<6>(a, pl.F, st); break;
         case 8: launch_encode<8>(a, pl.F, st); break;
         default: launch_encode<12>(a, pl.F, st); break;
     }
+    prof_end(0, st);
     int64_t* d_foff = reinterpret_cast<int64_t*>(ws + pl.off_foff);
     int64_t* d_snb = reinterpret_cast<int64_t*>(ws + pl.off_snb);
     int64_t* d_total = reinterpret_cast<int64_t*>(ws + pl.off_total);
@@ -357,9 +395,11 @@ int fa_encode_i32_device_finish(int64_t n_stream, int64_t stream_size, uint32_t 
                        stream_size, (int32_t)pl.P.blocksize, (int32_t)pl.tail_bs);
     int64_t nblk = (pl.F + 3) / 4;
     if (nblk > 8192) nblk = 8192;
+    prof_begin(1, st);
     hipLaunchKernelGGL(compact_frames_kernel, dim3((unsigned)nblk), dim3(256), 0, st,
                        reinterpret_cast<const uint8_t*>(ws + pl.off_slots),
                        reinterpret_cast<const uint32_t*>(ws + pl.off_fbytes), d_foff, d_starts, pl.nf, pl.F, crc, d_bytes);
+    prof_end(1, st);
     FA_HIP_TRY(hipGetLastError());
     return FA_ERROR_NONE;
 }

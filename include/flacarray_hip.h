@@ -114,6 +114,13 @@ int fa_float32_to_int32_device(const float* d_input, int64_t n_stream, int64_t s
 int fa_int32_to_float32_device(const int32_t* d_input, int64_t n_stream, int64_t stream_size, const float* d_offsets,
                                const float* d_gains, float* d_output, void* stream);
 
+/* Kernel timing for bench.py: when enabled, HIP events are recorded on the launch stream around
+ * the three dominant kernels of the most recent calls; fa_profile_last waits for them and
+ * returns milliseconds {encode_frames_kernel, compact_frames_kernel, decode_frames_kernel<8>}
+ * (-1 for a kernel that has not run). */
+void fa_profile_enable(int on);
+int fa_profile_last(float* ms3);
+
 /* free the library's cached device scratch (decode tables, staging buffers) */
 void fa_release_scratch(void);
 

@@ -98,7 +98,7 @@ def test_decode_oracle_streams(fa, oracle):
             d = fa.decode_flac_device(torch.from_numpy(blob).cuda(), torch.from_numpy(st).cuda(), torch.from_numpy(nb).cuda(), x.shape[1])
             assert np.array_equal(d.cpu().numpy(), x)
             n = x.shape[1]
-            for first, last in ((0, 1), (n // 2 - 5, n // 2 + 5), (4090, 8200), (n - 1, n), (1, n)):
+            for first, last in ((0, 1), (n // 2 - 5, n // 2 + 5), (4090, min(8200, n)), (n - 1, n), (1, n)):
                 d = fa.decode_flac_device(
                     torch.from_numpy(blob).cuda(), torch.from_numpy(st).cuda(), torch.from_numpy(nb).cuda(), n, first, last
                 )
@@ -144,7 +144,9 @@ def test_float_quantise_matches_oracle(fa, oracle):
         offsets=torch.from_numpy(offo), gains=torch.from_numpy(go),
     )
     assert np.array_equal(d.cpu().numpy().view(np.uint32), oracle.int32_to_float32(io, offo, go).view(np.uint32))
-    assert np.max(np.abs(d.cpu().numpy() - x) / q[:, None]) <= 0.5 + 1e-3
+    # |x^ - x| <= quanta/2 (+ ulps of |x| from the float32 subtract/add), as tests/array.py:251-260
+    tol = 0.5 * q[:, None] + 4 * np.finfo(np.float32).eps * np.abs(x)
+    assert np.all(np.abs(d.cpu().numpy() - x) <= tol)
 
 
 def test_scattered_slices(fa, oracle):
