@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libflacarray_hip.so")
+LIB_PATH = os.environ.get("FLACARRAY_HIP_LIB", os.path.join(_HERE, "lib", "libflacarray_hip.so"))
 
 # every symbol include/flacarray_hip.h declares
 SYMBOLS = [

@@ -31,15 +31,24 @@ def build(force=False, verbose=False):
     """Compile the library if it is missing or older than its sources; returns its path."""
     if not force and not needs_build():
         return OUT
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    return build_variant(None, [], verbose=verbose)
+
+
+def build_variant(name, defines, verbose=False):
+    """Compile a (diagnostic) variant lib/libflacarray_hip_<name>.so with extra -D flags."""
+    out = OUT if not name else OUT.replace(".so", f"_{name}.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", OUT + ".tmp", SRC]
+    cmd = [hipcc] + FLAGS + list(defines) + ["-o", out + ".tmp", SRC]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    os.replace(OUT + ".tmp", OUT)
-    return OUT
+    os.replace(out + ".tmp", out)
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--stamps" in sys.argv:
+        print(build_variant("stamps", ["-DFA_STAMPS"], verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

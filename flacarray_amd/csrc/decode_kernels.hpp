@@ -352,15 +352,108 @@ struct DecodeArgs {
     int* err;
 };
 
-constexpr int kTileSamples = 32;
-constexpr int kTileStride = 36;  // words per lane row in the LDS transpose tile
-constexpr int kFlagNeed12 = 1, kFlagNeed32 = 2;
+// ------------------------------------------------------------------------------------------
+// K7 (v2).  One wavefront = 64 frames, one LANE per frame, all lanes in lockstep on the sample
+// index.  LDS per wave (64-thread workgroup, ~15.5 KB -> 10 waves per CU):
+//   ring  64 x 36 words  per-lane input window: two 64-byte chunks of the frame's bytes stored
+//                        as big-endian words (+2 mirror words so a 3-word read never wraps);
+//                        topped up for ALL lanes together every 16 samples (a lane consumes at
+//                        most 64 bytes in 16 fast-path samples), so the per-sample code has no
+//                        refill branch: it re-reads its 96-bit window at `bitpos` from LDS
+//   tile  64 x 20 words  decoded samples, transposed so that HBM stores are 64-byte row pieces
+//   rows  64 descriptors output offset / valid range / (offset, 1/gain) of each lane's frame
+// Rare paths (headers, warm-up, partition parameters, escapes, codes longer than 32 bits) go
+// through two out-of-line helpers that take and return the reader state by value, so the hot
+// loop keeps `bitpos` in a register.
+// ------------------------------------------------------------------------------------------
+constexpr int kTileW = 16;
+constexpr int kTileStride = 20;
+constexpr int kRingStride = 36;
+constexpr int kFlagNeed16 = 1, kFlagNeed32 = 2;
 
-// MO = history depth of this variant (8, 12 or 32).  Tasks whose predictor order exceeds MO
-// are left for a later pass (flag word); tasks with order <= MO_DONE were done by an earlier one.
+__device__ __forceinline__ void ring_load_chunk(const uint8_t* cbase, const uint8_t* lim16, uint32_t* ring, uint32_t ci) {
+    const uint8_t* q = cbase + (size_t)ci * 64;
+    uint32_t* dst = ring + (ci & 1) * 16;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        uint4 d = make_uint4(0, 0, 0, 0);
+        if (q + 16 * v + 16 <= lim16) d = *reinterpret_cast<const uint4*>(q + 16 * v);
+        d.x = __builtin_bswap32(d.x); d.y = __builtin_bswap32(d.y); d.z = __builtin_bswap32(d.z); d.w = __builtin_bswap32(d.w);
+        *reinterpret_cast<uint4*>(dst + 4 * v) = d;
+        if (v == 0 && (ci & 1) == 0) { ring[32] = d.x; ring[33] = d.y; }  // mirror of words 0,1
+    }
+}
+// bits [bitpos, bitpos+32) -> A and [bitpos+32, bitpos+64) -> B
+__device__ __forceinline__ void ring_window(const uint32_t* ring, uint32_t bitpos, uint32_t& A, uint32_t& B) {
+    const uint32_t wi = (bitpos >> 5) & 31;
+    const uint32_t off = bitpos & 31;
+    const uint32_t w0 = ring[wi], w1 = ring[wi + 1], w2 = ring[wi + 2];
+    A = (uint32_t)((((((uint64_t)w0) << 32) | w1) << off) >> 32);
+    B = (uint32_t)((((((uint64_t)w1) << 32) | w2) << off) >> 32);
+}
+
+struct BitsRet {
+    uint32_t val, bitpos, next_chunk;
+};
+// read n (0..32) bits
+__device__ __noinline__ BitsRet slow_get(const uint8_t* cbase, const uint8_t* lim16, uint32_t* ring, uint32_t bitpos,
+                                         uint32_t next_chunk, int n) {
+    BitsRet r;
+    r.val = 0;
+    if (n > 0) {
+        while (((bitpos + 64) >> 9) >= next_chunk) { ring_load_chunk(cbase, lim16, ring, next_chunk); next_chunk++; }
+        uint32_t A, B;
+        ring_window(ring, bitpos, A, B);
+        r.val = A >> (32 - n);
+        bitpos += (uint32_t)n;
+    }
+    r.bitpos = bitpos;
+    r.next_chunk = next_chunk;
+    return r;
+}
+// count 0 bits up to and including the next 1 bit; val = number of zeros
+__device__ __noinline__ BitsRet slow_unary(const uint8_t* cbase, const uint8_t* lim16, uint32_t* ring, uint32_t bitpos,
+                                           uint32_t next_chunk) {
+    BitsRet r;
+    uint32_t q = 0;
+    for (;;) {
+        while (((bitpos + 64) >> 9) >= next_chunk) { ring_load_chunk(cbase, lim16, ring, next_chunk); next_chunk++; }
+        uint32_t A, B;
+        ring_window(ring, bitpos, A, B);
+        if (A) {
+            const int z = __clz((int)A);
+            bitpos += (uint32_t)z + 1;
+            q += (uint32_t)z;
+            break;
+        }
+        q += 32;
+        bitpos += 32;
+        if (q > (1u << 24)) break;  // corrupt stream guard: every lane reaches an exit
+    }
+    r.val = q;
+    r.bitpos = bitpos;
+    r.next_chunk = next_chunk;
+    return r;
+}
+
+#define FA_GET(n) ({ const BitsRet r_ = slow_get(cbase, lim16, ring, bitpos, next_chunk, (n)); bitpos = r_.bitpos; next_chunk = r_.next_chunk; r_.val; })
+#define FA_GETS(n) ({ const int n_ = (n); const uint32_t v_ = FA_GET(n_); (n_ == 0) ? 0 : ((int32_t)(v_ << (32 - n_)) >> (32 - n_)); })
+#define FA_UNARY() ({ const BitsRet r_ = slow_unary(cbase, lim16, ring, bitpos, next_chunk); bitpos = r_.bitpos; next_chunk = r_.next_chunk; r_.val; })
+
+// MO = history depth of this variant (8, 16 or 32).  Tasks whose predictor order exceeds MO are
+// left for a later pass (flag word); tasks with order <= MO_DONE were done by an earlier one.
 template <int MO, int MO_DONE>
-__device__ __forceinline__ void decode_wave(const DecodeArgs& a, int32_t* tile, int64_t* row_out, int2* row_rng, float2* row_fg,
-                                            int lane, int64_t task, bool has_task, int* flags) {
+__global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* flags) {
+    __shared__ __attribute__((aligned(16))) uint32_t rings[64 * kRingStride];
+    __shared__ __attribute__((aligned(16))) int32_t tile[64 * kTileStride];
+    __shared__ int64_t row_out[64];
+    __shared__ int2 row_rng[64];
+    __shared__ float2 row_fg[64];
+    const int lane = threadIdx.x;
+    const int64_t task = (int64_t)blockIdx.x * 64 + lane;
+    const bool has_task = task < a.n_tasks;
+    uint32_t* const ring = rings + lane * kRingStride;
+
     // ---- per-lane task setup ----
     int64_t s = 0, f = 0, sl_first = 0, sl_last = 0, out_off = 0;
     if (has_task) {
@@ -377,7 +470,6 @@ __device__ __forceinline__ void decode_wave(const DecodeArgs& a, int32_t* tile, 
     const int64_t fstart = f * (int64_t)a.B;
     int lo = 0, hi = 0;  // valid sample range inside this frame
     int bs = 0;
-    BitReader br;
     int mode = 3;  // 0 const, 1 verbatim, 2 predictive, 3 idle
     int order = 0, bps = 0, wasted = 0;
     int32_t cval = 0;
@@ -386,6 +478,10 @@ __device__ __forceinline__ void decode_wave(const DecodeArgs& a, int32_t* tile, 
 #pragma unroll
     for (int j = 0; j < MO; ++j) { c[j] = 0.0; h[j] = 0.0; }
     int plen = 4, esc = 15, ps = 0, pleft = 0, k = 0, escw = -1;
+    // reader state
+    const uint8_t* cbase = a.blob;
+    const uint8_t* const lim16 = reinterpret_cast<const uint8_t*>((reinterpret_cast<uintptr_t>(a.blob + a.blob_bytes) + 15) & ~(uintptr_t)15);
+    uint32_t bitpos = 0, next_chunk = 0x00400000u;  // idle lanes never refill
 
     if (has_task) {
         bool bad = false;
@@ -394,20 +490,68 @@ __device__ __forceinline__ void decode_wave(const DecodeArgs& a, int32_t* tile, 
         const int64_t at = a.ftab[s * a.nf + f];
         if (m.first_frame < 0 || at < 0) bad = true;
         else {
-            br.init(a.blob, a.blob + a.blob_bytes, a.blob + at);
-            const FrameHeader fh = read_frame_header(br, m.bps);
+            const uint8_t* start = a.blob + at;
+            cbase = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(start) & ~(uintptr_t)63);
+            if (cbase < a.blob) cbase = a.blob;  // the blob base is 16-byte aligned (host side guarantees it)
+            bitpos = (uint32_t)(start - cbase) * 8;
+            ring_load_chunk(cbase, lim16, ring, 0);
+            ring_load_chunk(cbase, lim16, ring, 1);
+            next_chunk = 2;
+            // ---- frame header (RFC 9639 9.1), CRC-8 verified ----
+            int fbs = 0, fbps = 0;
+            {
+                uint8_t c8 = 0;
+                const uint32_t w = FA_GET(32);
+                c8 = crc8_byte(c8, (uint8_t)(w >> 24));
+                c8 = crc8_byte(c8, (uint8_t)(w >> 16));
+                c8 = crc8_byte(c8, (uint8_t)(w >> 8));
+                c8 = crc8_byte(c8, (uint8_t)w);
+                if ((w >> 16) != 0xFFF8) bad = true;  // sync, reserved 0, fixed blocksize
+                const uint32_t b2 = (w >> 8) & 0xff, b3 = w & 0xff;
+                const int bsc = (int)(b2 >> 4), src = (int)(b2 & 15), ch = (int)(b3 >> 4), ssc = (int)((b3 >> 1) & 7);
+                if (ch != 0 || (b3 & 1)) bad = true;
+                const uint32_t u0 = FA_GET(8);
+                c8 = crc8_byte(c8, (uint8_t)u0);
+                int extra = 0;
+                if (u0 & 0x80) {
+                    int mbit = 0x40;
+                    while ((u0 & mbit) && extra < 7) { extra++; mbit >>= 1; }
+                    if (extra == 0 || extra > 6) bad = true;
+                }
+                for (int i = 0; i < extra && !bad; ++i) c8 = crc8_byte(c8, (uint8_t)FA_GET(8));
+                if (bsc == 0) bad = true;
+                else if (bsc == 1) fbs = 192;
+                else if (bsc <= 5) fbs = 576 << (bsc - 2);
+                else if (bsc == 6) { const uint32_t v = FA_GET(8); c8 = crc8_byte(c8, (uint8_t)v); fbs = (int)v + 1; }
+                else if (bsc == 7) { const uint32_t v = FA_GET(16); c8 = crc8_byte(c8, (uint8_t)(v >> 8)); c8 = crc8_byte(c8, (uint8_t)v); fbs = (int)v + 1; }
+                else fbs = 256 << (bsc - 8);
+                if (src == 12) { c8 = crc8_byte(c8, (uint8_t)FA_GET(8)); }
+                else if (src == 13 || src == 14) { const uint32_t v = FA_GET(16); c8 = crc8_byte(c8, (uint8_t)(v >> 8)); c8 = crc8_byte(c8, (uint8_t)v); }
+                else if (src == 15) bad = true;
+                if (FA_GET(8) != c8) bad = true;
+                switch (ssc) {
+                    case 0: fbps = m.bps; break;
+                    case 1: fbps = 8; break;
+                    case 2: fbps = 12; break;
+                    case 4: fbps = 16; break;
+                    case 5: fbps = 20; break;
+                    case 6: fbps = 24; break;
+                    case 7: fbps = 32; break;
+                    default: bad = true; break;
+                }
+            }
             int64_t expect = a.stream_size - fstart;
             if (expect > a.B) expect = a.B;
-            if (!fh.ok || fh.bs != (int)expect) bad = true;
-            else {
-                bs = fh.bs;
-                const uint32_t sf = br.get(8);
+            if (fbs != (int)expect) bad = true;
+            if (!bad) {
+                bs = fbs;
+                const uint32_t sf = FA_GET(8);
                 const int tc = (int)((sf >> 1) & 0x3f);
                 if (sf & 0x80) bad = true;
-                if (sf & 1) wasted = (int)br.unary() + 1;
-                bps = fh.bps - wasted;
+                if (sf & 1) wasted = (int)FA_UNARY() + 1;
+                bps = fbps - wasted;
                 if (bps <= 0 || bps > 32) bad = true;
-                else if (tc == 0) { mode = 0; cval = br.get_signed(bps); }
+                else if (tc == 0) { mode = 0; cval = FA_GETS(bps); }
                 else if (tc == 1) { mode = 1; }
                 else if (tc >= 8 && tc <= 12) { mode = 2; order = tc - 8; }
                 else if (tc >= 32) { mode = 2; order = (tc & 31) + 1; is_lpc = true; }
@@ -417,7 +561,7 @@ __device__ __forceinline__ void decode_wave(const DecodeArgs& a, int32_t* tile, 
         }
         if (!bad) {
             if (order > MO) {  // a later pass with a deeper history decodes this frame
-                atomicOr(flags, order > 12 ? kFlagNeed32 : kFlagNeed12);
+                atomicOr(flags, order > 16 ? kFlagNeed32 : kFlagNeed16);
                 mode = 3;
             } else if (order <= MO_DONE) {
                 mode = 3;  // decoded by an earlier pass
@@ -426,18 +570,18 @@ __device__ __forceinline__ void decode_wave(const DecodeArgs& a, int32_t* tile, 
         if (!bad && mode == 2) {
             // ---- warm-up samples, predictor description, residual header (serial per lane) ----
             for (int i = 0; i < order; ++i) {
-                const int32_t x = br.get_signed(bps);
-                tile[lane * kTileStride + i] = (int32_t)((uint32_t)x << wasted);
+                const int32_t x = FA_GETS(bps);
+                if (i < kTileW) tile[lane * kTileStride + i] = (int32_t)((uint32_t)x << wasted);
 #pragma unroll
                 for (int jj = 0; jj < MO; ++jj)
                     if (jj == (i % MO)) h[jj] = (double)x;
             }
             if (is_lpc) {
-                const int prec = (int)br.get(4) + 1;
-                const int sh = br.get_signed(5);
+                const int prec = (int)FA_GET(4) + 1;
+                const int sh = FA_GETS(5);
                 if (prec == 16 || sh < 0) bad = true;
                 for (int j = 0; j < order; ++j) {
-                    const double v = (double)br.get_signed(prec);
+                    const double v = (double)FA_GETS(prec);
 #pragma unroll
                     for (int jj = 0; jj < MO; ++jj)
                         if (jj == j) c[jj] = v;
@@ -449,8 +593,8 @@ __device__ __forceinline__ void decode_wave(const DecodeArgs& a, int32_t* tile, 
                 else if (order == 3) { c[0] = 3.0; c[1] = -3.0; c[2] = 1.0; }
                 else if (order == 4) { c[0] = 4.0; c[1] = -6.0; c[2] = 4.0; c[3] = -1.0; }
             }
-            const int method = (int)br.get(2);
-            const int po = (int)br.get(4);
+            const int method = (int)FA_GET(2);
+            const int po = (int)FA_GET(4);
             plen = method ? 5 : 4;
             esc = method ? 31 : 15;
             ps = bs >> po;
@@ -466,6 +610,7 @@ __device__ __forceinline__ void decode_wave(const DecodeArgs& a, int32_t* tile, 
             hi = (int)(h2 > l ? h2 : l);
         }
     }
+    if (mode == 3) { bs = 0; next_chunk = 0x00400000u; bitpos = 0; }
     // row descriptors for the cooperative store
     row_out[lane] = out_off + (fstart - sl_first);  // output element index of frame sample 0
     row_rng[lane] = make_int2(lo, hi);
@@ -480,24 +625,41 @@ __device__ __forceinline__ void decode_wave(const DecodeArgs& a, int32_t* tile, 
     const bool out_aligned = ((reinterpret_cast<uintptr_t>(a.out_f32 ? (const void*)a.out_f32 : (const void*)a.out_i32) & 15) == 0);
 
     const int bs_max = a.B;  // uniform loop bound (B >= every frame's blocksize)
-    for (int i0 = 0; i0 < bs_max; i0 += MO) {
+    constexpr int MACRO = (MO > 16) ? MO : 16;
+    for (int i0 = 0; i0 < bs_max; i0 += MACRO) {
 #pragma unroll
-        for (int u = 0; u < MO; ++u) {
+        for (int u = 0; u < MACRO; ++u) {
             const int i = i0 + u;
+            if ((u & 15) == 0) {
+                // all lanes together: the next 16 fast-path samples need at most 64 bytes
+                if ((bitpos >> 9) + 1 >= next_chunk) { ring_load_chunk(cbase, lim16, ring, next_chunk); next_chunk++; }
+                if ((bitpos >> 9) + 1 >= next_chunk) { ring_load_chunk(cbase, lim16, ring, next_chunk); next_chunk++; }
+            }
             if (i < bs) {
                 if (mode == 2) {
                     if (i >= order) {
                         if (pleft <= 0) {
-                            k = (int)br.get(plen);
+                            k = (int)FA_GET(plen);
                             escw = -1;
-                            if (k == esc) escw = (int)br.get(5);
+                            if (k == esc) escw = (int)FA_GET(5);
                             pleft += ps;
                         }
                         int32_t r;
-                        if (escw >= 0) r = br.get_signed(escw);
-                        else {
-                            const uint32_t q = br.unary();
-                            const uint32_t uu = (q << k) | (k ? br.get(k) : 0u);
+                        uint32_t A, Bw;
+                        ring_window(ring, bitpos, A, Bw);
+                        const int z = __clz((int)A);  // 32 when A == 0
+                        if (escw < 0 && A != 0 && z + 1 + k <= 32 && bitpos + 32 <= (next_chunk << 9)) {
+                            // fast path: the whole code lies inside the resident 32-bit window
+                            const uint64_t t = ((((uint64_t)A) << 32) | Bw) << (z + 1);
+                            const uint32_t low = k ? ((uint32_t)(t >> 32) >> (32 - k)) : 0u;
+                            const uint32_t uu = ((uint32_t)z << k) | low;
+                            r = (int32_t)(uu >> 1) ^ -(int32_t)(uu & 1);
+                            bitpos += (uint32_t)(z + 1 + k);
+                        } else if (escw >= 0) {
+                            r = FA_GETS(escw);
+                        } else {
+                            const uint32_t q = FA_UNARY();
+                            const uint32_t uu = (q << k) | FA_GET(k);
                             r = (int32_t)(uu >> 1) ^ -(int32_t)(uu & 1);
                         }
                         pleft--;
@@ -505,30 +667,33 @@ __device__ __forceinline__ void decode_wave(const DecodeArgs& a, int32_t* tile, 
 #pragma unroll
                         for (int j = 0; j < MO; ++j) sum = __builtin_fma(c[j], h[(u + MO - 1 - j) % MO], sum);
                         const double xd = (double)r + fa_floor(sum * scale);
-                        h[u] = xd;
-                        tile[lane * kTileStride + (i & (kTileSamples - 1))] = (int32_t)((uint32_t)(int32_t)xd << wasted);
+                        h[u % MO] = xd;
+                        tile[lane * kTileStride + (u & (kTileW - 1))] = (int32_t)((uint32_t)(int32_t)xd << wasted);
+                    } else if (i >= kTileW) {
+                        // warm-up sample 16..31 (orders above 16): its value sits in the history
+                        tile[lane * kTileStride + (u & (kTileW - 1))] = (int32_t)((uint32_t)(int32_t)h[u % MO] << wasted);
                     }
                 } else if (mode == 1) {
-                    const int32_t x = br.get_signed(bps);
-                    tile[lane * kTileStride + (i & (kTileSamples - 1))] = (int32_t)((uint32_t)x << wasted);
+                    const int32_t x = FA_GETS(bps);
+                    tile[lane * kTileStride + (u & (kTileW - 1))] = (int32_t)((uint32_t)x << wasted);
                 } else if (mode == 0) {
-                    tile[lane * kTileStride + (i & (kTileSamples - 1))] = (int32_t)((uint32_t)cval << wasted);
+                    tile[lane * kTileStride + (u & (kTileW - 1))] = (int32_t)((uint32_t)cval << wasted);
                 }
             }
-            if ((i & (kTileSamples - 1)) == kTileSamples - 1) {
-                // cooperative store of the tile: 8 rows x 32 samples per pass, 16 bytes per lane
+            if ((u & 15) == 15) {
+                // cooperative store of the tile: 16 rows x 16 samples per pass, 16 bytes per lane
                 __builtin_amdgcn_wave_barrier();
-                const int tbase = i & ~(kTileSamples - 1);
-#pragma unroll 2
-                for (int it = 0; it < 8; ++it) {
-                    const int r = it * 8 + (lane >> 3);
-                    const int cb = 4 * (lane & 7);
+                const int tbase = i & ~(kTileW - 1);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int r = it * 16 + (lane >> 2);
+                    const int cb = 4 * (lane & 3);
                     const int4 v = *reinterpret_cast<const int4*>(&tile[r * kTileStride + cb]);
                     const int2 rg = row_rng[r];
                     const int si = tbase + cb;
                     if (si + 3 >= rg.x && si < rg.y) {
                         const int64_t ob = row_out[r] + si;
-                        const bool full = (si >= rg.x) && (si + 3 < rg.y) && out_aligned && ((ob & 3) == 0);
+                        const bool fullv = (si >= rg.x) && (si + 3 < rg.y) && out_aligned && ((ob & 3) == 0);
                         if (a.out_f32) {
                             const float2 fg = row_fg[r];
                             float4 o;
@@ -536,7 +701,7 @@ __device__ __forceinline__ void decode_wave(const DecodeArgs& a, int32_t* tile, 
                             o.y = __fadd_rn(fg.x, __fmul_rn(fg.y, (float)v.y));
                             o.z = __fadd_rn(fg.x, __fmul_rn(fg.y, (float)v.z));
                             o.w = __fadd_rn(fg.x, __fmul_rn(fg.y, (float)v.w));
-                            if (full) *reinterpret_cast<float4*>(a.out_f32 + ob) = o;
+                            if (fullv) *reinterpret_cast<float4*>(a.out_f32 + ob) = o;
                             else {
                                 if (si + 0 >= rg.x && si + 0 < rg.y) a.out_f32[ob + 0] = o.x;
                                 if (si + 1 >= rg.x && si + 1 < rg.y) a.out_f32[ob + 1] = o.y;
@@ -544,7 +709,7 @@ __device__ __forceinline__ void decode_wave(const DecodeArgs& a, int32_t* tile, 
                                 if (si + 3 >= rg.x && si + 3 < rg.y) a.out_f32[ob + 3] = o.w;
                             }
                         } else {
-                            if (full) *reinterpret_cast<int4*>(a.out_i32 + ob) = v;
+                            if (fullv) *reinterpret_cast<int4*>(a.out_i32 + ob) = v;
                             else {
                                 if (si + 0 >= rg.x && si + 0 < rg.y) a.out_i32[ob + 0] = v.x;
                                 if (si + 1 >= rg.x && si + 1 < rg.y) a.out_i32[ob + 1] = v.y;
@@ -558,17 +723,6 @@ __device__ __forceinline__ void decode_wave(const DecodeArgs& a, int32_t* tile, 
             }
         }
     }
-}
-
-template <int MO, int MO_DONE>
-__global__ __launch_bounds__(256) void decode_frames_kernel(DecodeArgs a, int* flags) {
-    __shared__ __attribute__((aligned(16))) int32_t tiles[4][64 * kTileStride];
-    __shared__ int64_t row_out[4][64];
-    __shared__ int2 row_rng[4][64];
-    __shared__ float2 row_fg[4][64];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t task = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    decode_wave<MO, MO_DONE>(a, tiles[wave], row_out[wave], row_rng[wave], row_fg[wave], lane, task, task < a.n_tasks, flags);
 }
 
 }  // namespace fa

@@ -44,7 +44,39 @@ struct EncodeArgs {
     uint8_t* slots;         // [n_stream*nframes][kSlotBytes]
     uint32_t* frame_bytes;  // [n_stream*nframes]
     FrameInfo* info;        // [n_stream*nframes] or null
+    unsigned long long* stamps;  // diagnostic build (-DFA_STAMPS): per-phase cycle sums
 };
+
+#ifdef FA_STAMPS
+__device__ __forceinline__ unsigned long long fa_memtime() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define FA_STAMP(k)                                              \
+    do {                                                         \
+        const unsigned long long t_ = fa_memtime();              \
+        st_[k] += t_ - t_prev_;                                  \
+        t_prev_ = fa_memtime();                                  \
+    } while (0)
+#define FA_STAMP_INIT                 \
+    unsigned long long st_[16];       \
+    for (int i_ = 0; i_ < 16; ++i_) st_[i_] = 0; \
+    unsigned long long t_prev_ = fa_memtime()
+#define FA_STAMP_FLUSH                                                                   \
+    do {                                                                                 \
+        if (threadIdx.x == 0 && a.stamps && (blockIdx.x & 63) == 0) {                    \
+            for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&a.stamps[i_], st_[i_]);           \
+            atomicAdd(&a.stamps[16], 1ULL);                                              \
+        }                                                                                \
+    } while (0)
+#else
+#define FA_STAMP(k) do { } while (0)
+#define FA_STAMP_INIT do { } while (0)
+#define FA_STAMP_FLUSH do { } while (0)
+#endif
 
 constexpr int kChunkStride = 68;
 constexpr int kSmpWords = 65 * kChunkStride;  // 4420
@@ -54,37 +86,91 @@ constexpr int kLdsWords = kSmpWords + kRingWords + 128 + 16;  // 5076 words = 20
 
 __device__ __forceinline__ int smp_idx(int s) { return kChunkStride * ((s >> 6) + 1) + (s & 63); }
 
-// ---- wave-level helpers (64 lanes) -------------------------------------------------------
+// ---- wave-level helpers (64 lanes), DPP / swizzle based: no LDS traffic, no bpermute ---------
+// A single wavefront owns the whole workgroup, so cross-lane LDS hand-offs need only the LDS
+// queue drained (DS operations of one wave execute in order); s_barrier / vmcnt drains are
+// avoided on purpose: they would stall every row of the writer on its own global stores.
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+constexpr int kDppXor1 = 0xB1;    // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;    // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;  // == xor 4 once quads are uniform
+constexpr int kDppMirror = 0x140;      // == xor 8 once 8-lane groups are uniform
+constexpr int kSwzXor16 = 0x401F;      // ds_swizzle bit mode: and 0x1f, or 0, xor 0x10
+
+template <int STEP>
+__device__ __forceinline__ int xchg_i32(int v) {
+    if constexpr (STEP == 0) return dpp_i32<kDppXor1>(v);
+    else if constexpr (STEP == 1) return dpp_i32<kDppXor2>(v);
+    else if constexpr (STEP == 2) return dpp_i32<kDppHalfMirror>(v);
+    else if constexpr (STEP == 3) return dpp_i32<kDppMirror>(v);
+    else return __builtin_amdgcn_ds_swizzle(v, kSwzXor16);
+}
+template <int STEP>
+__device__ __forceinline__ double xchg_f64(double v) {
+    const int lo = xchg_i32<STEP>(__double2loint(v)), hi = xchg_i32<STEP>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+template <int STEP>
+__device__ __forceinline__ uint64_t xchg_u64(uint64_t v) {
+    const uint32_t lo = (uint32_t)xchg_i32<STEP>((int)(uint32_t)v), hi = (uint32_t)xchg_i32<STEP>((int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32) |
+           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+}
+
+// xor-butterfly sum: p[l] += p[l^1], ^2, ^4, ^8, ^16, ^32 -- the oracle's summation order
 __device__ __forceinline__ double wave_sum_butterfly(double v) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) v = v + __shfl_xor(v, off, 64);
-    return v;
+    v = v + xchg_f64<0>(v);
+    v = v + xchg_f64<1>(v);
+    v = v + xchg_f64<2>(v);
+    v = v + xchg_f64<3>(v);
+    v = v + xchg_f64<4>(v);
+    return readlane_f64(v, 0) + readlane_f64(v, 32);
 }
 __device__ __forceinline__ double wave_max_f64(double v) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        double o = __shfl_xor(v, off, 64);
-        v = (o > v) ? o : v;
-    }
-    return v;
+    double o;
+    o = xchg_f64<0>(v); v = (o > v) ? o : v;
+    o = xchg_f64<1>(v); v = (o > v) ? o : v;
+    o = xchg_f64<2>(v); v = (o > v) ? o : v;
+    o = xchg_f64<3>(v); v = (o > v) ? o : v;
+    o = xchg_f64<4>(v); v = (o > v) ? o : v;
+    const double a = readlane_f64(v, 0), b = readlane_f64(v, 32);
+    return (b > a) ? b : a;
 }
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) v += (uint64_t)__shfl_xor((unsigned long long)v, off, 64);
-    return v;
+    v += xchg_u64<0>(v);
+    v += xchg_u64<1>(v);
+    v += xchg_u64<2>(v);
+    v += xchg_u64<3>(v);
+    v += xchg_u64<4>(v);
+    return readlane_u64(v, 0) + readlane_u64(v, 32);
 }
 __device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) v |= (uint32_t)__shfl_xor((int)v, off, 64);
-    return v;
+    v |= (uint32_t)xchg_i32<0>((int)v);
+    v |= (uint32_t)xchg_i32<1>((int)v);
+    v |= (uint32_t)xchg_i32<2>((int)v);
+    v |= (uint32_t)xchg_i32<3>((int)v);
+    v |= (uint32_t)xchg_i32<4>((int)v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) | (uint32_t)__builtin_amdgcn_readlane((int)v, 32);
 }
-// inclusive prefix sum across the wave
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        uint32_t o = (uint32_t)__shfl_up((int)v, off, 64);
-        if (lane >= off) v += o;
-    }
+// inclusive prefix sum across the wave (row_shr scans inside each 16-lane row, then row_bcast)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1,3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2,3
     return v;
 }
 
@@ -184,17 +270,32 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
     const int nrows = (bs + kRow - 1) / kRow;
     const bool active = (kChunk * lane < bs);
 
+    FA_STAMP_INIT;
     // ---- P0: stage samples, wasted bits, constant test ---------------------------------
     for (int i = lane; i < kChunkStride; i += 64) smp[i] = 0;  // chunk -1 = zero history
     const int32_t first = src[0];
-    uint32_t orv;
-    bool alleq;
-    load_frame(src, bs, 0, smp, lane, &orv, &alleq, first);
+    uint32_t orv = 0;
+    bool alleq = true;
+    const bool full = (bs == kMaxBlock) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+    if (full) {
+        // all 16 row loads in flight at once (64 KB per CU outstanding at 8 waves)
+        int4 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<const int4*>(src + kRow * j + 4 * lane);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            orv |= (uint32_t)(v[j].x | v[j].y | v[j].z | v[j].w);
+            alleq = alleq && (v[j].x == first) && (v[j].y == first) && (v[j].z == first) && (v[j].w == first);
+            *reinterpret_cast<int4*>(&smp[smp_idx(kRow * j + 4 * lane)]) = v[j];
+        }
+    } else {
+        load_frame(src, bs, 0, smp, lane, &orv, &alleq, first);
+    }
     orv = wave_or_u32(orv);
     const bool is_const = __all(alleq);
     const int wasted = orv ? (__ffs((int)orv) - 1) : 0;
     const int bps = 32 - wasted;
-    __syncthreads();
+    lds_fence();
     if (wasted) {
         for (int j = 0; j < nrows; ++j) {
             int4* p = reinterpret_cast<int4*>(&smp[smp_idx(kRow * j + 4 * lane)]);
@@ -202,9 +303,10 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
             v.x >>= wasted; v.y >>= wasted; v.z >>= wasted; v.w >>= wasted;
             *p = v;
         }
-        __syncthreads();
+        lds_fence();
     }
 
+    FA_STAMP(0);
     const uint64_t verbatim_bits = 8 + (uint64_t)wasted + (uint64_t)bs * (uint64_t)bps;
     int type = 1;  // 0 const, 1 verbatim, 2 fixed, 3 lpc
     int order = 0, porder = 0, shift = 0, precision = 0;
@@ -258,6 +360,7 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                 }
             }
         }
+        FA_STAMP(1);
         {
             const double T0 = wave_sum_butterfly(tot0), T1 = wave_sum_butterfly(tot1), T2 = wave_sum_butterfly(tot2),
                          T3 = wave_sum_butterfly(tot3), T4 = wave_sum_butterfly(tot4);
@@ -271,15 +374,16 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
             if (M3 <= lim && T3 < smallest) { fo = 3; smallest = T3; }
             if (M4 <= lim && T4 < smallest) { fo = 4; smallest = T4; }
         }
+        FA_STAMP(2);
         int po_fix = 0, k_fix = 0;
         if (fo >= 0) {
             const double tl = (fo == 0) ? tot0 : (fo == 1) ? tot1 : (fo == 2) ? tot2 : (fo == 3) ? tot3 : tot4;
             const int pmax = max_porder_for(bs, a.max_porder, fo);
             const int lpp = (pmax == 0) ? 64 : ((bs >> pmax) / kChunk);
             psum[lane] = 0;
-            __syncthreads();
+            lds_fence();
             if (active) atomicAdd(reinterpret_cast<unsigned long long*>(&psum[lane / lpp]), (unsigned long long)tl);
-            __syncthreads();
+            lds_fence();
             const uint64_t S = psum[lane];
             const uint64_t est = 8 + (uint64_t)wasted + (uint64_t)fo * (uint64_t)bps +
                                  rice_search_wave((lane < (1 << pmax)) ? S : 0, bs, fo, pmax, lane, &po_fix, &k_fix);
@@ -290,9 +394,10 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                 porder = po_fix;
                 kbest = k_fix;
             }
-            __syncthreads();
+            lds_fence();
         }
 
+        FA_STAMP(3);
         // ---- P3: LPC analysis ----------------------------------------------------------
         if constexpr (MLO > 0) {
             int mlo = a.max_lpc_order;
@@ -304,27 +409,33 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                 if (active) {
                     const int cbase = kChunkStride * (lane + 1);
                     const int g0 = kChunk * lane;
+                    // the lane's 64 window values (and the MLO before them) are requested up
+                    // front so that one memory round trip covers the whole phase
+                    float4 wv[16];
+                    float wh[MLO];
+                    if (full) {
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) wv[t] = *reinterpret_cast<const float4*>(win + g0 + 4 * t);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) {
+                            const int gb = g0 + 4 * t;
+                            wv[t].x = (gb + 0 < bs) ? win[gb + 0] : 0.0f;
+                            wv[t].y = (gb + 1 < bs) ? win[gb + 1] : 0.0f;
+                            wv[t].z = (gb + 2 < bs) ? win[gb + 2] : 0.0f;
+                            wv[t].w = (gb + 3 < bs) ? win[gb + 3] : 0.0f;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < MLO; ++j) wh[j] = (g0 - 1 - j >= 0) ? win[g0 - 1 - j] : 0.0f;
                     double hist[MLO];  // hist[j] = d[i-1-j]
 #pragma unroll
-                    for (int j = 0; j < MLO; ++j) {
-                        const int gi = g0 - 1 - j;
-                        const int xi = smp[cbase - kChunkStride + 63 - j];
-                        const float wv = (gi >= 0) ? win[gi] : 0.0f;
-                        hist[j] = (double)xi * (double)wv;
-                    }
-#pragma unroll 4
+                    for (int j = 0; j < MLO; ++j) hist[j] = (double)smp[cbase - kChunkStride + 63 - j] * (double)wh[j];
+#pragma unroll
                     for (int t = 0; t < 16; ++t) {
                         int4 xv = *reinterpret_cast<const int4*>(&smp[cbase + 4 * t]);
-                        int xs[4] = {xv.x, xv.y, xv.z, xv.w};
-                        float ws[4];
-                        const int gb = g0 + 4 * t;
-                        if (gb + 3 < bs) {
-                            float4 wv = *reinterpret_cast<const float4*>(win + gb);
-                            ws[0] = wv.x; ws[1] = wv.y; ws[2] = wv.z; ws[3] = wv.w;
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) ws[e] = (gb + e < bs) ? win[gb + e] : 0.0f;
-                        }
+                        const int xs[4] = {xv.x, xv.y, xv.z, xv.w};
+                        const float ws[4] = {wv[t].x, wv[t].y, wv[t].z, wv[t].w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const double d = (double)xs[e] * (double)ws[e];
@@ -337,10 +448,12 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                         }
                     }
                 }
+                FA_STAMP(4);
                 double autoc[MLO + 1];
 #pragma unroll
                 for (int j = 0; j <= MLO; ++j) autoc[j] = wave_sum_butterfly(acc[j]);
 
+                FA_STAMP(5);
                 if (autoc[0] != 0.0) {
                     // scratch in the (still unused) ring area
                     float* coef = reinterpret_cast<float*>(ring);               // MLO*MLO floats
@@ -361,7 +474,8 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                         for (int j = lo; j < MLO; ++j) qc[j] = 0;
                         meta[0] = ok; meta[1] = lo; meta[2] = prec; meta[3] = sh;
                     }
-                    __syncthreads();
+                    lds_fence();
+                    FA_STAMP(6);
                     const int ok = meta[0], lo = meta[1], prec = meta[2], sh = meta[3];
                     if (ok) {
                         double qd[MLO];
@@ -403,15 +517,16 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                                 *px = make_int4(rs[0], rs[1], rs[2], rs[3]);
                             }
                         }
+                        FA_STAMP(7);
                         lds_is_residual = true;
                         const double MX = wave_max_f64(mxr);
                         const int pmax = max_porder_for(bs, a.max_porder, lo);
                         const int lpp = (pmax == 0) ? 64 : ((bs >> pmax) / kChunk);
-                        __syncthreads();
+                        lds_fence();
                         psum[lane] = 0;
-                        __syncthreads();
+                        lds_fence();
                         if (active) atomicAdd(reinterpret_cast<unsigned long long*>(&psum[lane / lpp]), (unsigned long long)tl);
-                        __syncthreads();
+                        lds_fence();
                         const uint64_t S = psum[lane];
                         int po_l = 0, k_l = 0;
                         const uint64_t rbits = rice_search_wave((lane < (1 << pmax)) ? S : 0, bs, lo, pmax, lane, &po_l, &k_l);
@@ -428,12 +543,13 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                             }
                         }
                     }
-                    __syncthreads();
+                    lds_fence();
                 }
             }
         }
     }
 
+    FA_STAMP(8);
     // LPC coefficients must survive the ring being recycled: keep them in registers
     int32_t qkeep[(MLO > 0) ? MLO : 1];
     if constexpr (MLO > 0) {
@@ -441,7 +557,7 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
 #pragma unroll
         for (int j = 0; j < MLO; ++j) qkeep[j] = (type == 3) ? qc[j] : 0;
     }
-    __syncthreads();
+    lds_fence();
 
     // ---- emit (with one possible VERBATIM retry) ---------------------------------------
     uint8_t* slot = a.slots + (size_t)g * kSlotBytes;
@@ -455,7 +571,7 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                 uint32_t o2; bool e2;
                 load_frame(src, bs, wasted, smp, lane, &o2, &e2, first);
                 lds_is_residual = false;
-                __syncthreads();
+                lds_fence();
             }
             if (type == 2 && order > 0) {
                 // fixed residual of order `order`, in place (history read before any write)
@@ -490,71 +606,76 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
         // Rice parameter table and ring reset
         kpar[lane] = (uint8_t)kbest;
         for (int i = lane; i < kRingWords; i += 64) ring[i] = 0;
-        __syncthreads();
+        lds_fence();
 
         bool rice2 = false;
         if (type >= 2) rice2 = __any((lane < (1 << porder)) && (kbest >= 15));
         const int plen = rice2 ? 5 : 4;
 
-        // ---- preamble by lane 0: frame header, subframe header, warm-up, LPC fields ----
+        FA_STAMP(9);
+        // ---- preamble: frame header, subframe header, warm-up, LPC fields, residual header ----
+        // Every value is wave-uniform: all lanes run the packer, lane 0 stores whole words
+        // (plain stores into the zeroed ring; the row writer ORs into the last partial word).
         uint32_t pos = 0;
-        if (lane == 0) {
-            uint8_t hdr[16];
-            int nh = 0;
-            const int bsc = blocksize_code(bs);
-            hdr[nh++] = 0xFF;
-            hdr[nh++] = 0xF8;
-            hdr[nh++] = (uint8_t)((bsc << 4) | 9);
-            hdr[nh++] = 0x0E;  // mono, 32 bits per sample, reserved 0
-            const uint64_t fn = (uint64_t)f;
-            if (fn < 0x80) hdr[nh++] = (uint8_t)fn;
-            else if (fn < 0x800) { hdr[nh++] = (uint8_t)(0xC0 | (fn >> 6)); hdr[nh++] = (uint8_t)(0x80 | (fn & 0x3F)); }
-            else if (fn < 0x10000) { hdr[nh++] = (uint8_t)(0xE0 | (fn >> 12)); hdr[nh++] = (uint8_t)(0x80 | ((fn >> 6) & 0x3F)); hdr[nh++] = (uint8_t)(0x80 | (fn & 0x3F)); }
-            else if (fn < 0x200000) { hdr[nh++] = (uint8_t)(0xF0 | (fn >> 18)); hdr[nh++] = (uint8_t)(0x80 | ((fn >> 12) & 0x3F)); hdr[nh++] = (uint8_t)(0x80 | ((fn >> 6) & 0x3F)); hdr[nh++] = (uint8_t)(0x80 | (fn & 0x3F)); }
-            else if (fn < 0x4000000) { hdr[nh++] = (uint8_t)(0xF8 | (fn >> 24)); hdr[nh++] = (uint8_t)(0x80 | ((fn >> 18) & 0x3F)); hdr[nh++] = (uint8_t)(0x80 | ((fn >> 12) & 0x3F)); hdr[nh++] = (uint8_t)(0x80 | ((fn >> 6) & 0x3F)); hdr[nh++] = (uint8_t)(0x80 | (fn & 0x3F)); }
-            else { hdr[nh++] = (uint8_t)(0xFC | (fn >> 30)); hdr[nh++] = (uint8_t)(0x80 | ((fn >> 24) & 0x3F)); hdr[nh++] = (uint8_t)(0x80 | ((fn >> 18) & 0x3F)); hdr[nh++] = (uint8_t)(0x80 | ((fn >> 12) & 0x3F)); hdr[nh++] = (uint8_t)(0x80 | ((fn >> 6) & 0x3F)); hdr[nh++] = (uint8_t)(0x80 | (fn & 0x3F)); }
-            if (bsc == 6) hdr[nh++] = (uint8_t)(bs - 1);
-            else if (bsc == 7) { hdr[nh++] = (uint8_t)((bs - 1) >> 8); hdr[nh++] = (uint8_t)(bs - 1); }
+        {
+            uint64_t acc = 0;
+            int nacc = 0;
+            uint32_t widx = 0;
             uint8_t c8 = 0;
-            for (int i = 0; i < nh; ++i) c8 = crc8_byte(c8, hdr[i]);
-            hdr[nh++] = c8;
-            for (int i = 0; i < nh; ++i) { ring_put(ring, pos, hdr[i], 8); pos += 8; }
+            auto put = [&](uint32_t v, int nb) {  // nb in 1..32
+                acc |= (uint64_t)v << (64 - nacc - nb);
+                nacc += nb;
+                if (nacc >= 32) {
+                    if (lane == 0) ring[widx] = (uint32_t)(acc >> 32);
+                    widx++;
+                    acc <<= 32;
+                    nacc -= 32;
+                }
+            };
+            auto put_hdr = [&](uint32_t byte) { c8 = crc8_byte(c8, (uint8_t)byte); put(byte & 0xffu, 8); };
+            const int bsc = blocksize_code(bs);
+            put_hdr(0xFF);
+            put_hdr(0xF8);
+            put_hdr((uint32_t)((bsc << 4) | 9));
+            put_hdr(0x0E);  // mono, 32 bits per sample, reserved 0
+            const uint64_t fn = (uint64_t)f;
+            if (fn < 0x80) put_hdr((uint32_t)fn);
+            else if (fn < 0x800) { put_hdr(0xC0 | (uint32_t)(fn >> 6)); put_hdr(0x80 | (uint32_t)(fn & 0x3F)); }
+            else if (fn < 0x10000) { put_hdr(0xE0 | (uint32_t)(fn >> 12)); put_hdr(0x80 | (uint32_t)((fn >> 6) & 0x3F)); put_hdr(0x80 | (uint32_t)(fn & 0x3F)); }
+            else if (fn < 0x200000) { put_hdr(0xF0 | (uint32_t)(fn >> 18)); put_hdr(0x80 | (uint32_t)((fn >> 12) & 0x3F)); put_hdr(0x80 | (uint32_t)((fn >> 6) & 0x3F)); put_hdr(0x80 | (uint32_t)(fn & 0x3F)); }
+            else if (fn < 0x4000000) { put_hdr(0xF8 | (uint32_t)(fn >> 24)); put_hdr(0x80 | (uint32_t)((fn >> 18) & 0x3F)); put_hdr(0x80 | (uint32_t)((fn >> 12) & 0x3F)); put_hdr(0x80 | (uint32_t)((fn >> 6) & 0x3F)); put_hdr(0x80 | (uint32_t)(fn & 0x3F)); }
+            else { put_hdr(0xFC | (uint32_t)(fn >> 30)); put_hdr(0x80 | (uint32_t)((fn >> 24) & 0x3F)); put_hdr(0x80 | (uint32_t)((fn >> 18) & 0x3F)); put_hdr(0x80 | (uint32_t)((fn >> 12) & 0x3F)); put_hdr(0x80 | (uint32_t)((fn >> 6) & 0x3F)); put_hdr(0x80 | (uint32_t)(fn & 0x3F)); }
+            if (bsc == 6) put_hdr((uint32_t)(bs - 1));
+            else if (bsc == 7) { put_hdr((uint32_t)((bs - 1) >> 8)); put_hdr((uint32_t)((bs - 1) & 0xff)); }
+            put((uint32_t)c8, 8);
             // subframe header
-            int tc = (type == 0) ? 0x00 : (type == 1) ? 0x01 : (type == 2) ? (0x08 | order) : (0x20 | (order - 1));
-            ring_put(ring, pos, (uint32_t)((tc << 1) | (wasted ? 1 : 0)), 8); pos += 8;
-            if (wasted) { pos += (uint32_t)(wasted - 1); ring_put(ring, pos, 1, 1); pos += 1; }
+            const int tc = (type == 0) ? 0x00 : (type == 1) ? 0x01 : (type == 2) ? (0x08 | order) : (0x20 | (order - 1));
+            put((uint32_t)((tc << 1) | (wasted ? 1 : 0)), 8);
+            if (wasted) {  // unary: wasted-1 zeros, then 1
+                for (int z = wasted - 1; z > 0;) { const int c = z > 16 ? 16 : z; put(0, c); z -= c; }
+                put(1, 1);
+            }
             const uint32_t mask = (bps == 32) ? 0xffffffffu : ((1u << bps) - 1u);
             if (type == 0) {
-                ring_put(ring, pos, (uint32_t)smp[smp_idx(0)] & mask, bps); pos += (uint32_t)bps;
+                put((uint32_t)smp[smp_idx(0)] & mask, bps);
             } else if (type >= 2) {
-                for (int i = 0; i < order; ++i) { ring_put(ring, pos, (uint32_t)smp[smp_idx(i)] & mask, bps); pos += (uint32_t)bps; }
+                for (int i = 0; i < order; ++i) put((uint32_t)smp[smp_idx(i)] & mask, bps);
                 if (type == 3) {
-                    ring_put(ring, pos, (uint32_t)(precision - 1), 4); pos += 4;
-                    ring_put(ring, pos, (uint32_t)shift, 5); pos += 5;
-                }
-            }
-        }
-        if constexpr (MLO > 0) {
-            if (type == 3) {
-                // coefficients live in registers (compile-time indices): lane 0 appends them
-                pos = (uint32_t)__shfl((int)pos, 0, 64);
+                    put((uint32_t)(precision - 1), 4);
+                    put((uint32_t)shift, 5);
+                    if constexpr (MLO > 0) {
 #pragma unroll
-                for (int j = 0; j < MLO; ++j) {
-                    if (j < order) {
-                        if (lane == 0) ring_put(ring, pos, (uint32_t)qkeep[j] & ((1u << precision) - 1u), precision);
-                        pos += (uint32_t)precision;
+                        for (int j = 0; j < MLO; ++j)
+                            if (j < order) put((uint32_t)qkeep[j] & ((1u << precision) - 1u), precision);
                     }
                 }
+                put(rice2 ? 1u : 0u, 2);
+                put((uint32_t)porder, 4);
             }
+            if (nacc > 0 && lane == 0) ring[widx] = (uint32_t)(acc >> 32);
+            pos = widx * 32 + (uint32_t)nacc;
         }
-        if (lane == 0 && type >= 2) {
-            ring_put(ring, pos, rice2 ? 1u : 0u, 2); pos += 2;
-            ring_put(ring, pos, (uint32_t)porder, 4); pos += 4;
-        }
-        pos = (uint32_t)__shfl((int)pos, 0, 64);
-        const uint32_t hdr_bits = (uint32_t)__shfl((int)0, 0, 64);  // placeholder to keep pos uniform
-        (void)hdr_bits;
-        __syncthreads();
+        lds_fence();
 
         // frame header bit count (needed for the exact subframe size): 8*(4 + utf8 + bs bytes + 1)
         uint32_t fh_bits;
@@ -565,6 +686,7 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
             fh_bits = 8u * (uint32_t)(4 + nb + (bsc == 6 ? 1 : bsc == 7 ? 2 : 0) + 1);
         }
 
+        FA_STAMP(10);
         // ---- rows: 4 consecutive samples per lane, scan of code lengths, OR into the ring ----
         bool overflow = false;
         uint32_t blocks_flushed = 0;
@@ -606,8 +728,8 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                     }
                     lane_len += ilen[e];
                 }
-                const uint32_t incl = wave_incl_scan_u32(lane_len, lane);
-                const uint32_t row_total = (uint32_t)__shfl((int)incl, 63, 64);
+                const uint32_t incl = wave_incl_scan_u32(lane_len);
+                const uint32_t row_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                 if (type >= 2 && row_total > (uint32_t)kRowCapBits) { overflow = true; break; }
                 uint32_t p = pos + incl - lane_len;
 #pragma unroll
@@ -620,7 +742,7 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                     }
                 }
                 pos += row_total;
-                __syncthreads();
+                lds_fence();
                 // flush completed 256-byte blocks
                 const uint32_t done = pos >> 11;
                 while (blocks_flushed < done) {
@@ -630,9 +752,10 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                     reinterpret_cast<uint32_t*>(slot)[blocks_flushed * 64 + lane] = __builtin_bswap32(wv);
                     blocks_flushed++;
                 }
-                __syncthreads();
+                lds_fence();
             }
         }
+        FA_STAMP(11);
         if (!overflow && type >= 2) {
             const uint64_t exact = (uint64_t)pos - fh_bits;
             if (exact > verbatim_bits) overflow = true;
@@ -654,6 +777,8 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
         }
         break;
     }
+    FA_STAMP(12);
+    FA_STAMP_FLUSH;
     if (lane == 0) {
         a.frame_bytes[g] = total_bytes;
         if (a.info) {

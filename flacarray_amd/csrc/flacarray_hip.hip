@@ -57,8 +57,8 @@ void prof_end(int k, hipStream_t st) {
 struct DeviceState {
     std::map<int, float*> windows;  // blocksize -> device tukey(0.5) table
     uint16_t* crc_tab = nullptr;
-    void* scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_bytes[6] = {0, 0, 0, 0, 0, 0};
+    void* scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 std::map<int, DeviceState> g_dev;
 
@@ -268,14 +268,14 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
         a.task_out_off = reinterpret_cast<const int64_t*>(c + 4 * stp);
     }
     if (a.B > kMaxBlock * 16) return FA_ERROR_DECODE_INIT;
-    const unsigned nblk = (unsigned)((a.n_tasks + 255) / 256);
+    const unsigned nblk = (unsigned)((a.n_tasks + 63) / 64);
     prof_begin(2, st);
-    hipLaunchKernelGGL((decode_frames_kernel<8, -1>), dim3(nblk), dim3(256), 0, st, a, d_err + 1);
+    hipLaunchKernelGGL((decode_frames_kernel<8, -1>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
     prof_end(2, st);
     FA_HIP_TRY(hipMemcpyAsync(h_err, d_err, 16, hipMemcpyDeviceToHost, st));
     FA_HIP_TRY(hipStreamSynchronize(st));
-    if (h_err[1] & kFlagNeed12) hipLaunchKernelGGL((decode_frames_kernel<12, 8>), dim3(nblk), dim3(256), 0, st, a, d_err + 1);
-    if (h_err[1] & kFlagNeed32) hipLaunchKernelGGL((decode_frames_kernel<32, 12>), dim3(nblk), dim3(256), 0, st, a, d_err + 1);
+    if (h_err[1] & kFlagNeed16) hipLaunchKernelGGL((decode_frames_kernel<16, 8>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
+    if (h_err[1] & kFlagNeed32) hipLaunchKernelGGL((decode_frames_kernel<32, 16>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
     if (h_err[1]) {
         FA_HIP_TRY(hipMemcpyAsync(h_err, d_err, 16, hipMemcpyDeviceToHost, st));
         FA_HIP_TRY(hipStreamSynchronize(st));
@@ -305,6 +305,16 @@ const char* fa_version(void) { return "flacarray_hip 0.1.0 (gfx950)"; }
 
 void fa_profile_enable(int on) { g_prof = (on != 0); }
 
+// diagnostic build only: read (and optionally clear) the per-phase cycle sums of K3
+int fa_debug_stamps(unsigned long long* out32, int reset) {
+    void* sp = nullptr;
+    if (get_scratch(6, 256, &sp)) return FA_ERROR_DEVICE;
+    if (hipDeviceSynchronize() != hipSuccess) return FA_ERROR_DEVICE;
+    if (hipMemcpy(out32, sp, 256, hipMemcpyDeviceToHost) != hipSuccess) return FA_ERROR_DEVICE;
+    if (reset && hipMemset(sp, 0, 256) != hipSuccess) return FA_ERROR_DEVICE;
+    return FA_ERROR_NONE;
+}
+
 int fa_profile_last(float* ms3) {
     for (int k = 0; k < 3; ++k) {
         ms3[k] = -1.0f;
@@ -327,7 +337,7 @@ void fa_release_scratch(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     DeviceState* st = dev_state();
     if (!st) return;
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < 8; ++i) {
         if (st->scratch[i]) (void)hipFree(st->scratch[i]);
         st->scratch[i] = nullptr;
         st->scratch_bytes[i] = 0;
@@ -360,6 +370,17 @@ int fa_encode_i32_device_begin(const int32_t* d_data, int64_t n_stream, int64_t 
     a.slots = reinterpret_cast<uint8_t*>(ws + pl.off_slots);
     a.frame_bytes = reinterpret_cast<uint32_t*>(ws + pl.off_fbytes);
     a.info = reinterpret_cast<FrameInfo*>(d_info);
+    a.stamps = nullptr;
+#ifdef FA_STAMPS
+    {
+        void* sp = nullptr;
+        static bool zeroed = false;
+        if (get_scratch(6, 256, &sp) == 0) {
+            if (!zeroed) { (void)hipMemset(sp, 0, 256); zeroed = true; }
+            a.stamps = reinterpret_cast<unsigned long long*>(sp);
+        }
+    }
+#endif
     prof_begin(0, st);
     switch (a.max_lpc_order) {
         case 0: launch_encode<0>(a, pl.F, st); break;

@@ -144,8 +144,8 @@ def test_float_quantise_matches_oracle(fa, oracle):
         offsets=torch.from_numpy(offo), gains=torch.from_numpy(go),
     )
     assert np.array_equal(d.cpu().numpy().view(np.uint32), oracle.int32_to_float32(io, offo, go).view(np.uint32))
-    # |x^ - x| <= quanta/2 (+ ulps of |x| from the float32 subtract/add), as tests/array.py:251-260
-    tol = 0.5 * q[:, None] + 4 * np.finfo(np.float32).eps * np.abs(x)
+    # |x^ - x| <= quanta/2 (+ ulps of |x|, |offset| from the float32 subtract/add), as tests/array.py:251-260
+    tol = 0.5 * q[:, None] + 4 * np.finfo(np.float32).eps * (np.abs(x) + np.abs(offo[:, None]))
     assert np.all(np.abs(d.cpu().numpy() - x) <= tol)
 
 
