@@ -18,6 +18,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "flac_math.hpp"
 
 namespace fa {
@@ -366,6 +369,15 @@ struct DecodeArgs {
 // through two out-of-line helpers that take and return the reader state by value, so the hot
 // loop keeps `bitpos` in a register.
 // ------------------------------------------------------------------------------------------
+template <int... U, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, U...>, F&& f) {
+    (f(std::integral_constant<int, U>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
 constexpr int kTileW = 16;
 constexpr int kTileStride = 20;
 constexpr int kRingStride = 36;
@@ -381,6 +393,30 @@ __device__ __forceinline__ void ring_load_chunk(const uint8_t* cbase, const uint
         d.x = __builtin_bswap32(d.x); d.y = __builtin_bswap32(d.y); d.z = __builtin_bswap32(d.z); d.w = __builtin_bswap32(d.w);
         *reinterpret_cast<uint4*>(dst + 4 * v) = d;
         if (v == 0 && (ci & 1) == 0) { ring[32] = d.x; ring[33] = d.y; }  // mirror of words 0,1
+    }
+}
+// the same in two halves, so that the global loads can be issued one chunk ahead of their use
+struct Chunk {
+    uint4 d[4];
+};
+__device__ __forceinline__ Chunk chunk_fetch(const uint8_t* cbase, const uint8_t* lim16, uint32_t ci) {
+    const uint8_t* q = cbase + (size_t)ci * 64;
+    Chunk c;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        c.d[v] = make_uint4(0, 0, 0, 0);
+        if (q + 16 * v + 16 <= lim16) c.d[v] = *reinterpret_cast<const uint4*>(q + 16 * v);
+    }
+    return c;
+}
+__device__ __forceinline__ void chunk_store(uint32_t* ring, uint32_t ci, const Chunk& c) {
+    uint32_t* dst = ring + (ci & 1) * 16;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        uint4 d = c.d[v];
+        d.x = __builtin_bswap32(d.x); d.y = __builtin_bswap32(d.y); d.z = __builtin_bswap32(d.z); d.w = __builtin_bswap32(d.w);
+        *reinterpret_cast<uint4*>(dst + 4 * v) = d;
+        if (v == 0 && (ci & 1) == 0) { ring[32] = d.x; ring[33] = d.y; }
     }
 }
 // bits [bitpos, bitpos+32) -> A and [bitpos+32, bitpos+64) -> B
@@ -610,7 +646,29 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
             hi = (int)(h2 > l ? h2 : l);
         }
     }
-    if (mode == 3) { bs = 0; next_chunk = 0x00400000u; bitpos = 0; }
+    // ---- unify every lane as a "predictive" lane so the sample loop has one code path ----
+    //   CONSTANT : order-1 predictor with c0 = 1 on h0 = value, zero-width escape residuals
+    //   VERBATIM : no predictor, escape residuals of width bps in one endless partition
+    //   idle     : zero-width escapes, nothing stored (empty row range)
+    if (mode == 3) { bs = 0x7fffffff; next_chunk = 0x00400000u; bitpos = 0; order = 0; escw = 0; pleft = 0x7fffffff; ps = 0; }
+    if (mode == 0) {
+#pragma unroll
+        for (int j = 0; j < MO; ++j) { c[j] = 0.0; h[j] = (double)cval; }
+        c[0] = 1.0; scale = 1.0; order = 0; escw = 0; pleft = 0x7fffffff;
+    }
+    if (mode == 1) {
+#pragma unroll
+        for (int j = 0; j < MO; ++j) c[j] = 0.0;
+        scale = 1.0; order = 0; escw = bps; pleft = 0x7fffffff;
+    }
+    // smallest blocksize in the wave decides where the guarded tail starts (idle lanes: huge)
+    int bs_min = bs;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_xor(bs_min, off, 64);
+        bs_min = o < bs_min ? o : bs_min;
+    }
+    bs_min = __builtin_amdgcn_readfirstlane(bs_min);
     // row descriptors for the cooperative store
     row_out[lane] = out_off + (fstart - sl_first);  // output element index of frame sample 0
     row_rng[lane] = make_int2(lo, hi);
@@ -623,105 +681,130 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
         row_fg[lane] = make_float2(og, cf);
     }
     const bool out_aligned = ((reinterpret_cast<uintptr_t>(a.out_f32 ? (const void*)a.out_f32 : (const void*)a.out_i32) & 15) == 0);
+    // chunk `pend_ci` is requested one chunk-time before it is stored into the ring
+    uint32_t pend_ci = next_chunk;
+    Chunk pend = chunk_fetch(cbase, lim16, pend_ci);
+    auto topup = [&]() __attribute__((always_inline)) {
+        if ((bitpos >> 9) + 1 >= next_chunk) {
+            if (pend_ci == next_chunk) chunk_store(ring, next_chunk, pend);
+            else ring_load_chunk(cbase, lim16, ring, next_chunk);  // a slow read overtook the prefetch
+            next_chunk++;
+            pend_ci = next_chunk;
+            pend = chunk_fetch(cbase, lim16, pend_ci);
+        }
+    };
+    int kf = (escw < 0) ? k : 64;  // fast-path key: z + kf < 32  <=>  plain Rice code of at most 32 bits
+
+    // one sample of every lane.  GUARD: lanes may be in warm-up or past their frame's end.
+    auto sample = [&](auto guard_tag, auto u_tag, int i) __attribute__((always_inline)) {
+        constexpr bool GUARD = decltype(guard_tag)::value;
+        constexpr int u = decltype(u_tag)::value;
+        bool live = true;
+        if constexpr (GUARD) {
+            live = (i < bs) && (i >= order);
+            if (i >= bs) { escw = 0; kf = 64; pleft = 0x7fffffff; }  // frame finished: consume nothing more
+        }
+        if (live) {
+            if (pleft <= 0) {
+                k = (int)FA_GET(plen);
+                escw = -1;
+                if (k == esc) escw = (int)FA_GET(5);
+                kf = (escw < 0) ? k : 64;
+                pleft += ps;
+                topup();  // a slow read may leave less than 64 resident bytes ahead
+            }
+            int32_t r;
+            uint32_t A, Bw;
+            ring_window(ring, bitpos, A, Bw);
+            const int z = __clz((int)A);  // 32 when A == 0
+            if (z + kf < 32) {
+                // fast path: the whole code (z zeros, stop bit, k low bits) lies inside A
+                const uint64_t t = ((((uint64_t)A) << 32) | Bw) << (z + 1);
+                const uint32_t low = k ? ((uint32_t)(t >> 32) >> (32 - k)) : 0u;
+                const uint32_t uu = ((uint32_t)z << k) | low;
+                r = (int32_t)(uu >> 1) ^ -(int32_t)(uu & 1);
+                bitpos += (uint32_t)(z + 1 + k);
+            } else if (escw == 0) {
+                r = 0;
+            } else if (escw > 0) {
+                r = FA_GETS(escw);
+                topup();
+            } else {
+                const uint32_t q = FA_UNARY();
+                const uint32_t uu = (q << k) | FA_GET(k);
+                r = (int32_t)(uu >> 1) ^ -(int32_t)(uu & 1);
+                topup();
+            }
+            pleft--;
+            double sum = 0.0;
+#pragma unroll
+            for (int j = 0; j < MO; ++j) sum = __builtin_fma(c[j], h[(u + MO - 1 - j) % MO], sum);
+            const double xd = (double)r + fa_floor(sum * scale);
+            h[u % MO] = xd;
+            tile[lane * kTileStride + (u & (kTileW - 1))] = (int32_t)((uint32_t)(int32_t)xd << wasted);
+        } else if constexpr (GUARD) {
+            // warm-up sample 16..31 (orders above 16): its value sits in the history
+            if (i < bs && i >= kTileW) tile[lane * kTileStride + (u & (kTileW - 1))] = (int32_t)((uint32_t)(int32_t)h[u % MO] << wasted);
+        }
+    };
+
+    // cooperative store of the tile: 16 rows x 16 samples per pass, 16 bytes per lane
+    auto flush_tile = [&](int tbase) __attribute__((always_inline)) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int r = it * 16 + (lane >> 2);
+            const int cb = 4 * (lane & 3);
+            const int4 v = *reinterpret_cast<const int4*>(&tile[r * kTileStride + cb]);
+            const int2 rg = row_rng[r];
+            const int si = tbase + cb;
+            if (si + 3 >= rg.x && si < rg.y) {
+                const int64_t ob = row_out[r] + si;
+                const bool fullv = (si >= rg.x) && (si + 3 < rg.y) && out_aligned && ((ob & 3) == 0);
+                if (a.out_f32) {
+                    const float2 fg = row_fg[r];
+                    float4 o;
+                    o.x = __fadd_rn(fg.x, __fmul_rn(fg.y, (float)v.x));  // utils.c:364
+                    o.y = __fadd_rn(fg.x, __fmul_rn(fg.y, (float)v.y));
+                    o.z = __fadd_rn(fg.x, __fmul_rn(fg.y, (float)v.z));
+                    o.w = __fadd_rn(fg.x, __fmul_rn(fg.y, (float)v.w));
+                    if (fullv) *reinterpret_cast<float4*>(a.out_f32 + ob) = o;
+                    else {
+                        if (si + 0 >= rg.x && si + 0 < rg.y) a.out_f32[ob + 0] = o.x;
+                        if (si + 1 >= rg.x && si + 1 < rg.y) a.out_f32[ob + 1] = o.y;
+                        if (si + 2 >= rg.x && si + 2 < rg.y) a.out_f32[ob + 2] = o.z;
+                        if (si + 3 >= rg.x && si + 3 < rg.y) a.out_f32[ob + 3] = o.w;
+                    }
+                } else {
+                    if (fullv) *reinterpret_cast<int4*>(a.out_i32 + ob) = v;
+                    else {
+                        if (si + 0 >= rg.x && si + 0 < rg.y) a.out_i32[ob + 0] = v.x;
+                        if (si + 1 >= rg.x && si + 1 < rg.y) a.out_i32[ob + 1] = v.y;
+                        if (si + 2 >= rg.x && si + 2 < rg.y) a.out_i32[ob + 2] = v.z;
+                        if (si + 3 >= rg.x && si + 3 < rg.y) a.out_i32[ob + 3] = v.w;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
 
     const int bs_max = a.B;  // uniform loop bound (B >= every frame's blocksize)
     constexpr int MACRO = (MO > 16) ? MO : 16;
     for (int i0 = 0; i0 < bs_max; i0 += MACRO) {
-#pragma unroll
-        for (int u = 0; u < MACRO; ++u) {
+        const bool guard = (i0 < 32) || (i0 + MACRO > bs_min);  // wave-uniform
+        static_for<MACRO>([&](auto ut) __attribute__((always_inline)) {
+            constexpr int u = decltype(ut)::value;
             const int i = i0 + u;
-            if ((u & 15) == 0) {
-                // all lanes together: the next 16 fast-path samples need at most 64 bytes
-                if ((bitpos >> 9) + 1 >= next_chunk) { ring_load_chunk(cbase, lim16, ring, next_chunk); next_chunk++; }
-                if ((bitpos >> 9) + 1 >= next_chunk) { ring_load_chunk(cbase, lim16, ring, next_chunk); next_chunk++; }
+            if constexpr ((u & 7) == 0) {
+                // all lanes together: the next 8 fast-path samples need at most 32 bytes, and at
+                // least 64 are resident after this top-up -> the sample code needs no residency test
+                topup();
             }
-            if (i < bs) {
-                if (mode == 2) {
-                    if (i >= order) {
-                        if (pleft <= 0) {
-                            k = (int)FA_GET(plen);
-                            escw = -1;
-                            if (k == esc) escw = (int)FA_GET(5);
-                            pleft += ps;
-                        }
-                        int32_t r;
-                        uint32_t A, Bw;
-                        ring_window(ring, bitpos, A, Bw);
-                        const int z = __clz((int)A);  // 32 when A == 0
-                        if (escw < 0 && A != 0 && z + 1 + k <= 32 && bitpos + 32 <= (next_chunk << 9)) {
-                            // fast path: the whole code lies inside the resident 32-bit window
-                            const uint64_t t = ((((uint64_t)A) << 32) | Bw) << (z + 1);
-                            const uint32_t low = k ? ((uint32_t)(t >> 32) >> (32 - k)) : 0u;
-                            const uint32_t uu = ((uint32_t)z << k) | low;
-                            r = (int32_t)(uu >> 1) ^ -(int32_t)(uu & 1);
-                            bitpos += (uint32_t)(z + 1 + k);
-                        } else if (escw >= 0) {
-                            r = FA_GETS(escw);
-                        } else {
-                            const uint32_t q = FA_UNARY();
-                            const uint32_t uu = (q << k) | FA_GET(k);
-                            r = (int32_t)(uu >> 1) ^ -(int32_t)(uu & 1);
-                        }
-                        pleft--;
-                        double sum = 0.0;
-#pragma unroll
-                        for (int j = 0; j < MO; ++j) sum = __builtin_fma(c[j], h[(u + MO - 1 - j) % MO], sum);
-                        const double xd = (double)r + fa_floor(sum * scale);
-                        h[u % MO] = xd;
-                        tile[lane * kTileStride + (u & (kTileW - 1))] = (int32_t)((uint32_t)(int32_t)xd << wasted);
-                    } else if (i >= kTileW) {
-                        // warm-up sample 16..31 (orders above 16): its value sits in the history
-                        tile[lane * kTileStride + (u & (kTileW - 1))] = (int32_t)((uint32_t)(int32_t)h[u % MO] << wasted);
-                    }
-                } else if (mode == 1) {
-                    const int32_t x = FA_GETS(bps);
-                    tile[lane * kTileStride + (u & (kTileW - 1))] = (int32_t)((uint32_t)x << wasted);
-                } else if (mode == 0) {
-                    tile[lane * kTileStride + (u & (kTileW - 1))] = (int32_t)((uint32_t)cval << wasted);
-                }
-            }
-            if ((u & 15) == 15) {
-                // cooperative store of the tile: 16 rows x 16 samples per pass, 16 bytes per lane
-                __builtin_amdgcn_wave_barrier();
-                const int tbase = i & ~(kTileW - 1);
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int r = it * 16 + (lane >> 2);
-                    const int cb = 4 * (lane & 3);
-                    const int4 v = *reinterpret_cast<const int4*>(&tile[r * kTileStride + cb]);
-                    const int2 rg = row_rng[r];
-                    const int si = tbase + cb;
-                    if (si + 3 >= rg.x && si < rg.y) {
-                        const int64_t ob = row_out[r] + si;
-                        const bool fullv = (si >= rg.x) && (si + 3 < rg.y) && out_aligned && ((ob & 3) == 0);
-                        if (a.out_f32) {
-                            const float2 fg = row_fg[r];
-                            float4 o;
-                            o.x = __fadd_rn(fg.x, __fmul_rn(fg.y, (float)v.x));  // utils.c:364
-                            o.y = __fadd_rn(fg.x, __fmul_rn(fg.y, (float)v.y));
-                            o.z = __fadd_rn(fg.x, __fmul_rn(fg.y, (float)v.z));
-                            o.w = __fadd_rn(fg.x, __fmul_rn(fg.y, (float)v.w));
-                            if (fullv) *reinterpret_cast<float4*>(a.out_f32 + ob) = o;
-                            else {
-                                if (si + 0 >= rg.x && si + 0 < rg.y) a.out_f32[ob + 0] = o.x;
-                                if (si + 1 >= rg.x && si + 1 < rg.y) a.out_f32[ob + 1] = o.y;
-                                if (si + 2 >= rg.x && si + 2 < rg.y) a.out_f32[ob + 2] = o.z;
-                                if (si + 3 >= rg.x && si + 3 < rg.y) a.out_f32[ob + 3] = o.w;
-                            }
-                        } else {
-                            if (fullv) *reinterpret_cast<int4*>(a.out_i32 + ob) = v;
-                            else {
-                                if (si + 0 >= rg.x && si + 0 < rg.y) a.out_i32[ob + 0] = v.x;
-                                if (si + 1 >= rg.x && si + 1 < rg.y) a.out_i32[ob + 1] = v.y;
-                                if (si + 2 >= rg.x && si + 2 < rg.y) a.out_i32[ob + 2] = v.z;
-                                if (si + 3 >= rg.x && si + 3 < rg.y) a.out_i32[ob + 3] = v.w;
-                            }
-                        }
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
+            if (guard) sample(std::true_type{}, ut, i);
+            else sample(std::false_type{}, ut, i);
+            if constexpr ((u & 15) == 15) flush_tile(i & ~(kTileW - 1));
+        });
     }
 }
 
