@@ -48,7 +48,10 @@ def build_variant(name, defines, verbose=False):
 
 
 if __name__ == "__main__":
-    if "--stamps" in sys.argv:
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:], verbose=True))
+    elif "--stamps" in sys.argv:
         print(build_variant("stamps", ["-DFA_STAMPS"], verbose=True))
     else:
         print(build(force="--force" in sys.argv, verbose=True))

@@ -254,7 +254,11 @@ __device__ __forceinline__ void load_frame(const int32_t* __restrict__ src, int 
 // ------------------------------------------------------------------------------------------
 template <int MLO>  // level's maximum LPC order: 0 (fixed predictors only), 6, 8 or 12
 __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
+#ifdef FA_LDS_PAD
+    __shared__ __attribute__((aligned(16))) int32_t lds[kLdsWords + FA_LDS_PAD];  // occupancy experiment
+#else
     __shared__ __attribute__((aligned(16))) int32_t lds[kLdsWords];
+#endif
     int32_t* smp = lds;
     uint32_t* ring = reinterpret_cast<uint32_t*>(lds + kSmpWords);
     uint64_t* psum = reinterpret_cast<uint64_t*>(lds + kSmpWords + kRingWords);
@@ -275,6 +279,7 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
     for (int i = lane; i < kChunkStride; i += 64) smp[i] = 0;  // chunk -1 = zero history
     const int32_t first = src[0];
     uint32_t orv = 0;
+    uint32_t absor = 0;  // OR of x ^ (x >> 31): bounds the magnitude of every sample
     bool alleq = true;
     const bool full = (bs == kMaxBlock) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
     if (full) {
@@ -285,13 +290,17 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             orv |= (uint32_t)(v[j].x | v[j].y | v[j].z | v[j].w);
+            absor |= (uint32_t)((v[j].x ^ (v[j].x >> 31)) | (v[j].y ^ (v[j].y >> 31)) | (v[j].z ^ (v[j].z >> 31)) | (v[j].w ^ (v[j].w >> 31)));
             alleq = alleq && (v[j].x == first) && (v[j].y == first) && (v[j].z == first) && (v[j].w == first);
             *reinterpret_cast<int4*>(&smp[smp_idx(kRow * j + 4 * lane)]) = v[j];
         }
     } else {
         load_frame(src, bs, 0, smp, lane, &orv, &alleq, first);
+        absor = 0xffffffffu;  // generic path: no narrow shortcut
     }
     orv = wave_or_u32(orv);
+    absor = wave_or_u32(absor);
+    const bool narrow = absor < (1u << 24);  // every |x| < 2^24: fixed-predictor errors fit 32-bit ints
     const bool is_const = __all(alleq);
     const int wasted = orv ? (__ffs((int)orv) - 1) : 0;
     const int bps = 32 - wasted;
@@ -322,7 +331,52 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
         // ---- P2: fixed predictors 0..4 over the lane's chunk (exact in double) ---------
         double tot0 = 0.0, tot1 = 0.0, tot2 = 0.0, tot3 = 0.0, tot4 = 0.0;
         double mx0 = 0.0, mx1 = 0.0, mx2 = 0.0, mx3 = 0.0, mx4 = 0.0;
-        if (active) {
+        if (active && narrow) {
+            // 32-bit integer path: |e_k| < 2^28, so a 16-sample u32 partial sum cannot overflow and
+            // every order is valid.  v_sad_u32 on sign-biased values gives |a - b| + acc in one op.
+            const int cbase = kChunkStride * (lane + 1);
+            const int4 hh = *reinterpret_cast<const int4*>(&smp[cbase - kChunkStride + 60]);
+            const uint32_t BIAS = 0x80000000u;
+            int p1 = hh.w;
+            int pe1 = hh.w - hh.z;
+            int pe2 = pe1 - (hh.z - hh.y);
+            int pe3 = pe2 - ((hh.z - hh.y) - (hh.y - hh.x));
+            uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+            const int g0 = kChunk * lane;
+            for (int t4 = 0; t4 < 4; ++t4) {
+                uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    const int t = 4 * t4 + tt;
+                    const int4 xv = *reinterpret_cast<const int4*>(&smp[cbase + 4 * t]);
+                    const int xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int gi = g0 + 4 * t + e;
+                        const int x = xs[e];
+                        const int e1 = x - p1, e2 = e1 - pe1, e3 = e2 - pe2;
+                        const uint32_t n0 = __usad((uint32_t)x ^ BIAS, BIAS, s0);
+                        const uint32_t n1 = __usad((uint32_t)x ^ BIAS, (uint32_t)p1 ^ BIAS, s1);
+                        const uint32_t n2 = __usad((uint32_t)e1 ^ BIAS, (uint32_t)pe1 ^ BIAS, s2);
+                        const uint32_t n3 = __usad((uint32_t)e2 ^ BIAS, (uint32_t)pe2 ^ BIAS, s3);
+                        const uint32_t n4 = __usad((uint32_t)e3 ^ BIAS, (uint32_t)pe3 ^ BIAS, s4);
+                        if (full && t > 0) {
+                            s0 = n0; s1 = n1; s2 = n2; s3 = n3; s4 = n4;
+                        } else {
+                            const bool v = gi < bs;
+                            s0 = v ? n0 : s0;
+                            s1 = (v && gi >= 1) ? n1 : s1;
+                            s2 = (v && gi >= 2) ? n2 : s2;
+                            s3 = (v && gi >= 3) ? n3 : s3;
+                            s4 = (v && gi >= 4) ? n4 : s4;
+                        }
+                        p1 = x; pe1 = e1; pe2 = e2; pe3 = e3;
+                    }
+                }
+                a0 += s0; a1 += s1; a2 += s2; a3 += s3; a4 += s4;
+            }
+            tot0 = (double)a0; tot1 = (double)a1; tot2 = (double)a2; tot3 = (double)a3; tot4 = (double)a4;
+        } else if (active) {
             const int cbase = kChunkStride * (lane + 1);
             int4 h = *reinterpret_cast<const int4*>(&smp[cbase - kChunkStride + 60]);
             double p1 = (double)h.w;
@@ -688,71 +742,99 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
 
         FA_STAMP(10);
         // ---- rows: 4 consecutive samples per lane, scan of code lengths, OR into the ring ----
+        // Branch-free per item: an item that does not exist (warm-up sample, past the end of the
+        // frame) has length 0 and ORs zeros.
         bool overflow = false;
         uint32_t blocks_flushed = 0;
-        if (type != 0) {
-            const uint32_t ps = (uint32_t)(bs >> porder);
-            const uint32_t magic = (uint32_t)((0x100000000ULL + ps - 1) / ps);  // floor(gi/ps) = umulhi(gi, magic)
+        auto put_bits = [&](uint32_t P, uint32_t val, uint32_t nb) __attribute__((always_inline)) {
+            // val has nb (1..32) significant bits; place it at absolute bit position P
+            const uint32_t off = P & 31u;
+            const uint64_t X = (uint64_t)val << (64u - nb - off);
+            const uint32_t a0 = (P >> 3) & 0x7FCu;  // byte offset of the word inside the 2 KB ring
+            const uint32_t a1 = (a0 + 4u) & 0x7FCu;
+            atomicOr(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ring) + a0), (uint32_t)(X >> 32));
+            atomicOr(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ring) + a1), (uint32_t)X);
+        };
+        auto flush_blocks = [&]() __attribute__((always_inline)) {
+            // no fence: DS operations of one wavefront are processed in issue order, so these
+            // reads see every earlier ds_or of this wave
+            const uint32_t done = pos >> 11;
+            while (blocks_flushed < done) {
+                const uint32_t wi = (blocks_flushed * 64 + lane) & kRingMask;
+                const uint32_t wv = ring[wi];
+                ring[wi] = 0;
+                reinterpret_cast<uint32_t*>(slot)[blocks_flushed * 64 + lane] = __builtin_bswap32(wv);
+                blocks_flushed++;
+            }
+        };
+        if (type == 1) {
             const uint32_t mask = (bps == 32) ? 0xffffffffu : ((1u << bps) - 1u);
             for (int j = 0; j < nrows; ++j) {
                 const int gb = kRow * j + 4 * lane;
-                int4 rv = *reinterpret_cast<const int4*>(&smp[smp_idx(gb)]);
-                int rs[4] = {rv.x, rv.y, rv.z, rv.w};
-                uint32_t ilen[4], iq[4], ival[4], ipre[4];
-                int inb[4];
-                uint32_t lane_len = 0;
-                int k = 0;
-                uint32_t pidx = 0;
-                if (type >= 2) {
-                    pidx = __umulhi((uint32_t)gb, magic);
-                    k = kpar[pidx];
+                const int4 rv = *reinterpret_cast<const int4*>(&smp[smp_idx(gb)]);
+                const int rs[4] = {rv.x, rv.y, rv.z, rv.w};
+                int nvalid = bs - gb;
+                nvalid = nvalid < 0 ? 0 : (nvalid > 4 ? 4 : nvalid);
+                const uint32_t lane_len = (uint32_t)(nvalid * bps);
+                const uint32_t incl = wave_incl_scan_u32(lane_len);
+                const uint32_t row_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                uint32_t p = pos + incl - lane_len;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t v = (e < nvalid) ? ((uint32_t)rs[e] & mask) : 0u;
+                    put_bits(p, v, (uint32_t)bps);
+                    p += (e < nvalid) ? (uint32_t)bps : 0u;
                 }
+                pos += row_total;
+                flush_blocks();
+            }
+        } else if (type >= 2) {
+            const uint32_t ps = (uint32_t)(bs >> porder);
+            const uint32_t magic = (uint32_t)((0x100000000ULL + ps - 1) / ps);  // floor(gi/ps) = umulhi(gi, magic)
+            for (int j = 0; j < nrows; ++j) {
+                const int gb = kRow * j + 4 * lane;
+                const int4 rv = *reinterpret_cast<const int4*>(&smp[smp_idx(gb)]);
+                const int rs[4] = {rv.x, rv.y, rv.z, rv.w};
+                const uint32_t pidx = __umulhi((uint32_t)gb, magic);
+                const uint32_t k = kpar[pidx];
+                const uint32_t pstart = (pidx == 0) ? (uint32_t)order : pidx * ps;
+                uint32_t iq[4], ival[4], ilen[4];
+                uint32_t lane_len = 0;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int gi = gb + e;
-                    ilen[e] = 0; iq[e] = 0; ival[e] = 0; ipre[e] = 0; inb[e] = 0;
-                    if (gi < bs) {
-                        if (type == 1) {
-                            inb[e] = bps;
-                            ival[e] = (uint32_t)rs[e] & mask;
-                            ilen[e] = (uint32_t)bps;
-                        } else if (gi >= order) {
-                            const uint32_t u = ((uint32_t)rs[e] << 1) ^ (uint32_t)(rs[e] >> 31);
-                            iq[e] = u >> k;
-                            inb[e] = k + 1;
-                            ival[e] = (1u << k) | (u & ((1u << k) - 1u));
-                            const uint32_t pstart = (pidx == 0) ? (uint32_t)order : pidx * ps;
-                            ipre[e] = ((uint32_t)gi == pstart) ? (uint32_t)plen : 0u;
-                            ilen[e] = ipre[e] + iq[e] + (uint32_t)k + 1u;
-                        }
-                    }
+                    const bool valid = (gi >= order) && (gi < bs);
+                    const uint32_t u = ((uint32_t)rs[e] << 1) ^ (uint32_t)(rs[e] >> 31);
+                    const uint32_t q = u >> k;
+                    const uint32_t val = (1u << k) | (u & ((1u << k) - 1u));
+                    const uint32_t pre = ((uint32_t)gi == pstart) ? (uint32_t)plen : 0u;
+                    iq[e] = valid ? (q + pre) : 0u;  // zeros before the stop bit (+ room for the parameter)
+                    ival[e] = valid ? val : 0u;
+                    ilen[e] = valid ? (q + pre + k + 1u) : 0u;
                     lane_len += ilen[e];
                 }
                 const uint32_t incl = wave_incl_scan_u32(lane_len);
                 const uint32_t row_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                if (type >= 2 && row_total > (uint32_t)kRowCapBits) { overflow = true; break; }
+                if (row_total > (uint32_t)kRowCapBits) { overflow = true; break; }
                 uint32_t p = pos + incl - lane_len;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (ilen[e]) {
-                        if (ipre[e]) { ring_put(ring, p, (uint32_t)k, plen); p += ipre[e]; }
-                        p += iq[e];
-                        ring_put(ring, p, ival[e], inb[e]);
-                        p += (uint32_t)inb[e];
+                // the (at most one) partition parameter this lane owns in this row
+                {
+                    const uint32_t de = pstart - (uint32_t)gb;  // 0..3 if the partition starts in this lane's group
+                    if (de < 4u && (int)pstart >= order && (int)pstart < bs) {
+                        uint32_t pp = p;
+                        if (de > 0) pp += ilen[0];
+                        if (de > 1) pp += ilen[1];
+                        if (de > 2) pp += ilen[2];
+                        put_bits(pp, k, (uint32_t)plen);
                     }
                 }
-                pos += row_total;
-                lds_fence();
-                // flush completed 256-byte blocks
-                const uint32_t done = pos >> 11;
-                while (blocks_flushed < done) {
-                    const uint32_t wi = (blocks_flushed * 64 + lane) & kRingMask;
-                    const uint32_t wv = ring[wi];
-                    ring[wi] = 0;
-                    reinterpret_cast<uint32_t*>(slot)[blocks_flushed * 64 + lane] = __builtin_bswap32(wv);
-                    blocks_flushed++;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    put_bits(p + iq[e], ival[e], k + 1u);
+                    p += ilen[e];
                 }
-                lds_fence();
+                pos += row_total;
+                flush_blocks();
             }
         }
         FA_STAMP(11);
