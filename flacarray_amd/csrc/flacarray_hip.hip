@@ -192,6 +192,14 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
                        const int64_t* slice_stream, const int64_t* slice_first, const int64_t* slice_count,
                        const int64_t* out_offset, int32_t* d_out_i32, float* d_out_f32, const float* d_offsets,
                        const float* d_gains, hipStream_t st) {
+    // the decode kernel issues 16-byte loads relative to the blob base: realign if necessary
+    if (reinterpret_cast<uintptr_t>(d_bytes) & 15) {
+        void* al = nullptr;
+        int rc0 = get_scratch(7, (size_t)n_bytes + 256, &al);
+        if (rc0) return rc0;
+        FA_HIP_TRY(hipMemcpyAsync(al, d_bytes, (size_t)n_bytes, hipMemcpyDeviceToDevice, st));
+        d_bytes = reinterpret_cast<const unsigned char*>(al);
+    }
     // ---- K6: parse stream headers ----
     void* p = nullptr;
     const size_t meta_bytes = align_up((size_t)n_stream * sizeof(StreamMeta), 256);

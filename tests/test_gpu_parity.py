@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import full_range_i32, sinusoid_noise_f32, sinusoid_noise_i32
+from tests.conftest import full_range_i32, sinusoid_noise_f32, sinusoid_noise_i32
 
 pytestmark = pytest.mark.gpu
 
@@ -164,3 +164,71 @@ def test_scattered_slices(fa, oracle):
     out = out.cpu().numpy()
     for i in range(n):
         assert np.array_equal(out[off[i] : off[i] + cnt[i]], x[ch[i], first[i] : first[i] + cnt[i]]), i
+
+
+GOLDEN_NAMES = ["g1_const", "g2_verbatim", "g3_fixed", "g4_lpc", "g5_wasted", "g6_16bit", "g7_deep"]
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_decode_hand_assembled_streams(fa, name):
+    """Streams assembled field by field from RFC 9639 (tests/golden/make_golden.py): no SEEKTABLE
+    (frame walk), 8/16-bit blocksize codes, escapes, Rice2, wasted bits, 16/24-bit samples,
+    predictor orders 12 and 20 (deeper-history passes), metadata blocks to skip."""
+    import os
+
+    import torch
+
+    v = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "flac_vectors.npz"))
+    s, st, n = v[name + "_samples"], v[name + "_stream"], int(v[name + "_size"])
+    # three copies in one blob, addressed out of order, the blob deliberately not 16-byte aligned
+    blob = np.concatenate([np.zeros(3, np.uint8), st, st, st])
+    starts = np.array([3 + 2 * st.size, 3, 3 + st.size], dtype=np.int64)
+    nbytes = np.full(3, st.size, dtype=np.int64)
+    d = fa.decode_flac_device(torch.from_numpy(blob).cuda()[3:], torch.from_numpy(starts - 3).cuda(), torch.from_numpy(nbytes).cuda(), n)
+    assert np.array_equal(d.cpu().numpy(), np.stack([s, s, s]))
+    y = fa.decode_flac(blob, starts, nbytes, n)  # host C ABI
+    assert np.array_equal(y, np.stack([s, s, s]))
+    for first, last in ((0, 1), (n // 2, n), (max(n - 3, 0), n)):
+        if first < last:
+            y = fa.decode_flac(blob, starts, nbytes, n, first_sample=first, last_sample=last)
+            assert np.array_equal(y, np.stack([s[first:last]] * 3)), (first, last)
+
+
+def test_corrupt_stream_reports_error(fa, oracle):
+    x = sinusoid_noise_i32(2, 9000, seed=1)
+    blob, st, nb = oracle.encode_i32(x, 5)
+    bad = blob.copy()
+    bad[int(st[1]) + 0] ^= 0xFF  # break the "fLaC" marker of stream 1
+    with pytest.raises(RuntimeError, match="Decoding failed"):
+        fa.decode_flac(bad, st, nb, 9000)
+    bad = blob.copy()
+    bad[int(st[0]) + 100 + 2] ^= 0x10  # frame header byte of stream 0's first frame: CRC-8 mismatch
+    with pytest.raises(RuntimeError, match="Decoding failed"):
+        fa.decode_flac(bad, st, nb, 9000)
+
+
+def test_float_array_path(fa, oracle):
+    """array_compress / array_decompress on float32 (quanta scalar, per-stream array, precision)."""
+    x = sinusoid_noise_f32(6, 30000, seed=12).reshape(2, 3, 30000)
+    for kw in ({"quanta": 1e-4}, {"quanta": np.full((2, 3), 2e-4, np.float32)}, {"precision": 4}):
+        comp, starts, nbytes, off, gain = fa.array_compress(x, level=5, **kw)
+        y = fa.array_decompress(comp, 30000, starts, nbytes, stream_offsets=off, stream_gains=gain)
+        q = 1.0 / gain
+        assert np.all(np.abs(y - x) <= 0.5 * q[..., None] + 8 * np.finfo(np.float32).eps * (np.abs(x) + np.abs(off[..., None])))
+    with pytest.raises(RuntimeError, match="NaNs"):
+        bad = x.copy()
+        bad[1, 1, 77] = np.nan
+        fa.array_compress(bad, quanta=1e-4)
+
+
+def test_read_slices_batched(fa):
+    x = sinusoid_noise_i32(24, 20000, seed=31).reshape(4, 6, 20000)
+    f = fa.FlacArray.from_array(x)
+    rng = np.random.default_rng(2)
+    streams = rng.integers(0, 24, 64)
+    cnt = rng.integers(1, 9000, 64)
+    first = np.array([rng.integers(0, 20000 - c + 1) for c in cnt])
+    outs = f.read_slices(streams, first, cnt)
+    flat = x.reshape(24, -1)
+    for i in range(64):
+        assert np.array_equal(outs[i], flat[streams[i], first[i] : first[i] + cnt[i]])

@@ -1,0 +1,193 @@
+"""CPU tests of the host side: C-ABI exports, validation and error text, selection helpers, the
+FlacArray surface.  Compute calls need a GPU; here the four binding-level wrappers are replaced
+by a TEST-ONLY stand-in built on the oracle so the Python logic above them runs on the CPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import flacarray_amd as fa
+from tests.conftest import ROOT, full_range_i32, sinusoid_noise_i32
+from flacarray_amd import _lib, libflacarray
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "flacarray_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:int64_t|int|void|const char\*)\s+(\w+)\(", header, flags=re.M))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for sym in declared:
+        assert hasattr(L, sym), sym
+    assert b"gfx950" in _lib.lib().fa_version()
+
+
+def test_no_silent_cpu_fallback():
+    if _lib.lib().fa_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        fa.array_compress(np.zeros((2, 100), np.int32))
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        fa.decode_flac(np.zeros(10, np.uint8), np.zeros(1, np.int64), np.zeros(1, np.int64), 10)
+    # the raw C ABI reports FA_ERROR_DEVICE instead of computing on the host
+    x = np.zeros(8, np.int32)
+    nb, raw, st = ctypes.c_int64(0), ctypes.c_void_p(None), np.zeros(1, np.int64)
+    rc = _lib.lib().encode_i32(x.ctypes.data, 1, 8, 5, ctypes.byref(nb), st.ctypes.data, ctypes.byref(raw))
+    assert rc == _lib.ERROR_DEVICE and raw.value is None
+
+
+def test_encode_decode_validation_text():
+    """libflacarray.pyx:551-559, :751-789"""
+    with pytest.raises(RuntimeError, match="Only 32bit or 64bit integer data is supported"):
+        fa.encode_flac(np.zeros((2, 8), np.float32), 5)
+    with pytest.raises(RuntimeError, match="Only C-contiguous arrays are supported"):
+        fa.encode_flac(np.zeros((8, 2), np.int32).T, 5)
+    with pytest.raises(RuntimeError, match="FLAC only supports compression levels 0-8"):
+        fa.encode_flac(np.zeros((2, 8), np.int32), 9)
+    c, s, n = np.zeros(10, np.uint8), np.zeros(1, np.int64), np.zeros(1, np.int64)
+    with pytest.raises(RuntimeError, match="Compressed data should be of type uint8"):
+        fa.decode_flac(c.astype(np.int8), s, n, 10)
+    with pytest.raises(RuntimeError, match="starts data should be of type int64"):
+        fa.decode_flac(c, s.astype(np.int32), n, 10)
+    with pytest.raises(RuntimeError, match="nbytes data should be of type int64"):
+        fa.decode_flac(c, s, n.astype(np.int32), 10)
+    with pytest.raises(RuntimeError, match="non-zero output stream size"):
+        fa.decode_flac(c, s, n, 0)
+    with pytest.raises(RuntimeError, match="one dimensional"):
+        fa.decode_flac(c.reshape(2, 5), s, n, 10)
+    with pytest.raises(RuntimeError, match="last_sample is beyond end of stream"):
+        fa.decode_flac(c, s, n, 10, 0, 11)
+    with pytest.raises(RuntimeError, match="first_sample is beyond last element of stream"):
+        fa.decode_flac(c, s, n, 10, 10, 10)
+    with pytest.raises(RuntimeError, match="first_sample is larger than last_sample"):
+        fa.decode_flac(c, s, n, 10, 5, 5)
+
+
+def test_array_compress_argument_errors():
+    """compress.py:47-59,84"""
+    with pytest.raises(ValueError, match="zero-sized"):
+        fa.array_compress(np.zeros((0, 4), np.int32))
+    with pytest.raises(RuntimeError, match="requires specifying either quanta or precision"):
+        fa.array_compress(np.zeros((2, 4), np.float32))
+    with pytest.raises(RuntimeError, match="Cannot set both quanta and precision"):
+        fa.array_compress(np.zeros((2, 4), np.float32), quanta=1e-3, precision=3)
+    with pytest.raises(ValueError, match="Unsupported data type"):
+        fa.array_compress(np.zeros((2, 4), np.int16))
+    with pytest.raises(NotImplementedError):
+        fa.encode_flac(np.zeros((2, 4), np.int64), 5)
+
+
+def test_keep_select_matches_reference_semantics():
+    rng = np.random.default_rng(1)
+    starts = rng.integers(0, 1000, (4, 3)).astype(np.int64)
+    nbytes = rng.integers(1, 50, (4, 3)).astype(np.int64)
+    keep = rng.random((4, 3)) > 0.5
+    s, n, idx = fa.keep_select(keep, starts, nbytes)
+    # the reference walks np.nditer in C order with multi_index (utils.py:432-449)
+    exp = [(i, j) for i in range(4) for j in range(3) if keep[i, j]]
+    assert idx == exp and s.dtype == np.int64 and s.tolist() == [starts[i] for i in exp] and n.tolist() == [nbytes[i] for i in exp]
+    assert fa.keep_select(None, starts, nbytes) == (starts, nbytes, None)
+    with pytest.raises(RuntimeError, match="same shape as stream_starts"):
+        fa.keep_select(keep[:2], starts, nbytes)
+    from flacarray_amd.utils import select_keep_indices
+
+    off = rng.random((4, 3)).astype(np.float32)
+    assert select_keep_indices(off, idx).tolist() == [off[i] for i in exp]
+    assert select_keep_indices(None, idx) is None and select_keep_indices(off, None) is off
+
+
+def test_shard_range_is_array_split():
+    from flacarray_amd.dist import shard_counts, shard_range
+
+    for n in (1, 7, 8, 4096, 32768, 10):
+        for w in (1, 2, 3, 8):
+            parts = np.array_split(np.arange(n), w)  # mpi.py:84
+            for r in range(w):
+                lo, hi = shard_range(n, w, r)
+                assert hi - lo == len(parts[r]) and (hi == lo or parts[r][0] == lo)
+            assert sum(shard_counts(n, w)) == n
+
+
+# ---- TEST-ONLY CPU stand-in for the binding layer (the oracle), to exercise the Python logic ----
+@pytest.fixture
+def cpu_backend(monkeypatch, oracle):
+    def enc(flat, n_stream, stream_size, level):
+        return oracle.encode_i32(np.asarray(flat).reshape(n_stream, stream_size), level)
+
+    def dec(comp, starts, nbytes, n_stream, stream_size, first, last, use_threads):
+        return oracle.decode_i32(comp, starts, nbytes, stream_size, first, last).reshape(-1)
+
+    def f2i(flat, n_stream, stream_size, quanta):
+        q = quanta if len(quanta) == n_stream else None
+        o, off, g = oracle.float32_to_int32(np.asarray(flat).reshape(n_stream, stream_size), q)
+        return o.reshape(-1), off, g
+
+    def i2f(idata, n_stream, stream_size, offsets, gains):
+        return oracle.int32_to_float32(np.asarray(idata).reshape(n_stream, stream_size), offsets, gains).reshape(-1)
+
+    import flacarray_amd.utils as U
+
+    monkeypatch.setattr(libflacarray, "wrap_encode_i32", enc)
+    monkeypatch.setattr(libflacarray, "wrap_encode_i32_threaded", enc)
+    monkeypatch.setattr(libflacarray, "wrap_decode_i32", dec)
+    monkeypatch.setattr(U, "wrap_float32_to_int32", f2i)
+    monkeypatch.setattr(U, "wrap_int32_to_float32", i2f)
+    return oracle
+
+
+def _check_array_surface():
+    """tests/array.py:26-146 (helpers), :167-232 (slicing shapes) restated."""
+    for shape in ((4, 3, 1000), (10000,)):
+        x = full_range_i32(shape)
+        comp, starts, nbytes, off, gain = fa.array_compress(x, level=5)
+        assert off is None and gain is None  # tests/array.py:57-60
+        lead = shape[:-1] if len(shape) > 1 else (1,)
+        assert starts.shape == lead and nbytes.shape == lead and comp.dtype == np.uint8
+        y = fa.array_decompress(comp, shape[-1], starts, nbytes)
+        assert y.shape == x.shape and np.array_equal(y, x)
+        n = shape[-1]
+        y = fa.array_decompress(comp, n, starts, nbytes, first_stream_sample=n // 2 - 5, last_stream_sample=n // 2 + 5)
+        assert np.array_equal(y, x[..., n // 2 - 5 : n // 2 + 5])
+        xf = (np.random.default_rng(0).normal(0, 1, shape)).astype(np.float32)
+        comp, starts, nbytes, off, gain = fa.array_compress(xf, level=5, quanta=1e-6)
+        assert off.shape == lead and gain.shape == lead and off.dtype == np.float32
+        yf = fa.array_decompress(comp, n, starts, nbytes, stream_offsets=off, stream_gains=gain)
+        assert yf.dtype == np.float32 and np.allclose(yf, xf, atol=1e-5)  # tests/array.py: atol = 10 * quanta
+    # numpy-style slicing: shapes must equal numpy's (tests/array.py:167-232)
+    x = sinusoid_noise_i32(120, 100, seed=8).reshape(4, 3, 10, 100)
+    f = fa.FlacArray.from_array(x)
+    assert f.shape == x.shape and f.stream_size == 100 and f.leading_shape == (4, 3, 10) and f.dtype == np.int32
+    keys = [
+        (slice(None), slice(None), slice(None), slice(None)), (1, slice(None)), (slice(1, 3), 2), (0, 1, 2),
+        (0, 1, 2, 5), (slice(None), 1, slice(2, 8), slice(10, 20)), (3, slice(None), slice(None), slice(50, None)),
+        (slice(0, 0),), (1, 2, slice(None), slice(99, 100)), 2, (slice(None), slice(None), 9, slice(None, 10)),
+        (0, 0, 0, slice(40, 40)),
+    ]
+    for key in keys:
+        assert f[key].shape == x[key].shape, key
+        assert np.array_equal(f[key], x[key]), key
+    x1 = sinusoid_noise_i32(1, 10000, seed=9)[0]
+    f1 = fa.FlacArray.from_array(x1)
+    for key in (slice(None), slice(100, 200), 77):
+        assert np.array_equal(f1[key], x1[key]) and np.shape(f1[key]) == np.shape(x1[key])
+    # to_array with keep mask + indices (array.py:518-584)
+    keep = np.zeros((4, 3, 10), bool)
+    keep[1, 2, 3] = keep[3, 0, 9] = True
+    arr, idx = f.to_array(keep=keep, keep_indices=True)
+    assert idx == [(1, 2, 3), (3, 0, 9)] and np.array_equal(arr, np.stack([x[1, 2, 3], x[3, 0, 9]]))
+    assert np.array_equal(f.to_array(stream_slice=slice(10, 20)), x[..., 10:20])
+    assert np.array_equal(f.to_array(), x) and f == fa.FlacArray(f)
+    with pytest.raises(RuntimeError):
+        f[0] = 1
+    with pytest.raises(ValueError, match="stride==1"):
+        f[0, 0, 0, ::2]
+
+
+def test_array_surface_cpu_standin(cpu_backend):
+    _check_array_surface()
+
+
+@pytest.mark.gpu
+def test_array_surface_gpu():
+    _check_array_surface()

@@ -1,0 +1,138 @@
+"""CPU tests: the oracle against the independent golden vectors and the reference's own test recipes."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from tests.conftest import full_range_i32, sinusoid_noise_f32, sinusoid_noise_i32
+from tests.golden import pyflac
+from tests.golden.make_golden import build as build_golden, crc8, crc16
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "flac_vectors.npz")
+NAMES = ["g1_const", "g2_verbatim", "g3_fixed", "g4_lpc", "g5_wasted", "g6_16bit", "g7_deep"]
+
+
+def test_crc_known_answers():
+    assert crc8(b"123456789") == 0xF4  # CRC-8/SMBUS check value
+    assert crc16(b"123456789") == 0xFEE8  # CRC-16/UMTS check value
+
+
+def test_golden_file_matches_generator():
+    v = np.load(GOLDEN)
+    g = build_golden()
+    for k in g:
+        assert np.array_equal(v[k], g[k]), k
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_decodes_hand_assembled_streams(oracle, name):
+    v = np.load(GOLDEN)
+    s, st, n = v[name + "_samples"], v[name + "_stream"], int(v[name + "_size"])
+    starts, nbytes = np.array([0], dtype=np.int64), np.array([st.size], dtype=np.int64)
+    assert np.array_equal(oracle.decode_i32(st, starts, nbytes, n)[0], s)
+    for first, last in ((0, 1), (n // 2, n), (max(n - 3, 0), n)):
+        if first < last:
+            assert np.array_equal(oracle.decode_i32(st, starts, nbytes, n, first, last)[0], s[first:last])
+    # two copies in one blob, addressed out of order (keep-mask style starts/nbytes)
+    blob = np.concatenate([st, st])
+    out = oracle.decode_i32(blob, np.array([st.size, 0]), np.array([st.size, st.size]), n)
+    assert np.array_equal(out[0], s) and np.array_equal(out[1], s)
+
+
+@pytest.mark.parametrize("level", range(9))
+def test_oracle_encoder_read_by_independent_decoder(oracle, level):
+    x = sinusoid_noise_i32(1, 9000, seed=level, amp=2**14)[0]
+    blob, st, nb = oracle.encode_i32(x, level)
+    y, info = pyflac.decode_stream(blob.tobytes())
+    assert y == x.tolist()
+    bs = 1152 if level <= 2 else 4096
+    assert info["min_bs"] == info["max_bs"] == bs and info["bps"] == 32 and info["total"] == 9000 and info["channels"] == 1
+    # the SEEKTABLE is a complete frame index
+    assert len(info["seektable"]) == len(info["frames"])
+    for f, (sn, off, ns) in enumerate(info["seektable"]):
+        assert sn == f * bs and ns == info["frames"][f]["bs"] and off == info["frames"][f]["offset"] - info["first_frame"]
+
+
+def test_oracle_adversarial_streams_read_by_independent_decoder(oracle):
+    rng = np.random.default_rng(3)
+    cases = [full_range_i32((1, 5000))[0], np.zeros(4500, np.int32), np.full(4097, 2**31 - 1, np.int32),
+             (np.arange(6000) * 1024).astype(np.int32), rng.integers(-2, 3, 4096).astype(np.int32)]
+    spikes = rng.integers(-3, 4, 8192).astype(np.int32)
+    spikes[100], spikes[5000] = 2**31 - 1, -(2**31)
+    cases.append(spikes)
+    for x in cases:
+        blob, st, nb = oracle.encode_i32(x, 5)
+        y, info = pyflac.decode_stream(blob.tobytes())
+        assert y == x.tolist()
+
+
+def test_reference_binding_recipe_roundtrip(oracle):
+    """tests/bindings.py:27-93 restated with a seed: 3 x 10000 full-range int32 with the extremes."""
+    x = full_range_i32((3, 10000))
+    x[0, 0], x[0, 1] = -2147483647, 2147483647
+    blob, st, nb = oracle.encode_i32(x, 5, use_threads=True)
+    assert np.array_equal(oracle.decode_i32(blob, st, nb, 10000), x)
+    assert np.array_equal(oracle.decode_i32(blob, st, nb, 10000, 4995, 5005), x[:, 4995:5005])
+
+
+@pytest.mark.parametrize("n", [1, 2, 4, 5, 15, 16, 4095, 4096, 4097, 1000000])
+def test_lengths_roundtrip(oracle, n):
+    rng = np.random.default_rng(n)
+    x = np.cumsum(rng.integers(-100, 101, n)).astype(np.int32)
+    blob, st, nb = oracle.encode_i32(x, 5)
+    assert np.array_equal(oracle.decode_i32(blob, st, nb, n)[0], x)
+    assert blob.size == nb.sum() and st[0] == 0
+
+
+def test_argument_errors(oracle):
+    x = np.zeros((2, 10), np.int32)
+    with pytest.raises(RuntimeError, match="return code = 2"):  # ERROR_INVALID_LEVEL, compress.c:144
+        oracle.encode_i32(x, 9)
+    blob, st, nb = oracle.encode_i32(x, 5)
+    for first, last in ((0, 11), (10, 11), (5, 5)):  # decompress.c:209-222
+        with pytest.raises(RuntimeError, match=str(1 << 17)):
+            oracle.decode_i32(blob, st, nb, 10, first, last)
+
+
+def test_det_log2(oracle):
+    L = oracle.lib()
+    for v in (1.0, 2.0, 0.5, 3.0, 1e-20, 7.123e40, 1.4142135623730951, 1.4142135623730954):
+        assert abs(L.oracle_det_log2(v) - math.log2(v)) < 1e-13 * max(1.0, abs(math.log2(v)))
+
+
+# ---- float quantisation: the reference's own test properties (tests/array.py:234-283, tests/utils.py:66-108) ----
+def test_quantization_error_bound(oracle):
+    rng = np.random.default_rng(0)
+    quanta = np.float32(1e-3)
+    for dc in (0.0, 0.5, -0.5, 10.0, -10.0, -10.51, -10.4):
+        x = (rng.normal(0, 1, (2, 1000)) + dc).astype(np.float32)
+        i, off, g = oracle.float32_to_int32(x, np.full(2, quanta, np.float32))
+        y = oracle.int32_to_float32(i, off, g)
+        assert np.max(np.abs(y - x)) <= 0.5 * quanta + 8 * np.finfo(np.float32).eps * (abs(dc) + 5)
+        # data already on the quantisation grid comes back within 2 max|x| eps
+        xq = (np.rint(x / quanta) * quanta).astype(np.float32)
+        i, off, g = oracle.float32_to_int32(xq, np.full(2, quanta, np.float32))
+        y = oracle.int32_to_float32(i, off, g)
+        assert np.max(np.abs(y - xq)) <= 2 * np.max(np.abs(xq)) * np.finfo(np.float32).eps + quanta * 1e-3
+
+
+def test_quantization_rules(oracle):
+    x = sinusoid_noise_f32(4, 2000, seed=2)
+    x[1] = 0.0
+    i, off, g = oracle.float32_to_int32(x, None)  # auto quanta from the data range (utils.c:194-203)
+    assert g[1] == 1.0 and off[1] == 0.0 and np.all(i[1] == 0)  # all-zero stream (utils.c:224-228)
+    assert np.abs(i).max() <= 2147483647 and np.abs(i[0]).max() > 2**30  # full dynamic range used
+    y = oracle.int32_to_float32(i, off, g)
+    assert np.allclose(y, x, rtol=1e-5, atol=1e-5)
+    # explicit per-stream quanta: gain = 1/quanta, offset a whole number of quanta (utils.c:221-230)
+    q = np.array([1e-5, 2e-5, 3e-5, 4e-5], np.float32)
+    i, off, g = oracle.float32_to_int32(x, q)
+    assert np.allclose(g, 1.0 / q, rtol=1e-6)
+    ratio = off.astype(np.float64) / q.astype(np.float64)
+    assert np.allclose(ratio, np.rint(ratio), atol=1e-2)
+    # rounding is half away from zero of (gain * (x - off)) computed in float (utils.c:232-240)
+    k = 7
+    st = np.float32(x[0, k] - off[0])
+    pr = np.float32(g[0] * st)
+    assert i[0, k] == int(np.float64(pr) + (0.5 if st >= 0 else -0.5))
