@@ -47,6 +47,25 @@ def make_data(torch, n_ch, n_samp, seed, device):
     return out
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the most recent committed PMC measurement
+    (profiles/r*_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+    command, corrected as MI355X_MICROARCH.md prescribes); None if there is none."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    try:
+        data = json.load(open(files[-1]))
+        for name, rec in data["kernels"].items():
+            if kernel in name:
+                return round(rec["hbm_bytes"] / 1e9, 3)
+    except Exception:
+        return None
+    return None
+
+
 def cpu_baseline(n_samp, seconds_budget=25.0):
     """Time the CPU oracle (a port, not libFLAC: libFLAC is absent from this image) on a bounded
     sample of the same workload with every host core."""
@@ -192,10 +211,13 @@ def main():
                 "bound": "hbm",
                 "kernel": dom,
                 "achieved": achieved,
+                "algorithmic_GB_per_launch": round((4 + c_bytes) * n_local / 1e9, 3),
+                "ms_per_launch": kernels[dom]["ms"],
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": measured_traffic(dom) if (n_ch, n_samp) == (4096, 1 << 20) else None,
+                "traffic_unit": "GB per launch (PMC, profiles/r*_traffic.json)",
                 "algorithmic_bytes_per_sample": round(4 + c_bytes, 4),
             },
             "kernels": kernels,
