@@ -108,14 +108,18 @@ static void bw_reserve(bitw_t *w, uint64_t more_bits) {
     w->buf = nb;
     w->cap = ncap;
 }
-/* write the low n bits of v (n <= 64) */
+/* write the low n bits of v (n <= 64), a byte at a time */
 static void bw_put(bitw_t *w, uint64_t v, unsigned n) {
     if (n == 0) return;
-    bw_reserve(w, n);
+    if (((w->nbits + n + 7) >> 3) + 8 > w->cap) bw_reserve(w, n);
     if (w->err) return;
-    for (int b = (int)n - 1; b >= 0; --b) {
-        if ((v >> b) & 1) w->buf[w->nbits >> 3] |= (uint8_t)(0x80 >> (w->nbits & 7));
-        w->nbits++;
+    while (n) {
+        const unsigned bitoff = (unsigned)(w->nbits & 7), room = 8 - bitoff;
+        const unsigned take = n < room ? n : room;
+        const uint8_t bits = (uint8_t)((v >> (n - take)) & ((1u << take) - 1u));
+        w->buf[w->nbits >> 3] |= (uint8_t)(bits << (room - take));
+        w->nbits += take;
+        n -= take;
     }
 }
 static void bw_zeros(bitw_t *w, uint64_t n) {
@@ -744,10 +748,14 @@ typedef struct {
 
 static uint64_t br_get(bitr_t *r, unsigned n) {
     uint64_t v = 0;
-    for (unsigned i = 0; i < n; ++i) {
-        if ((r->pos >> 3) >= r->nbytes) { r->err = 1; return 0; }
-        v = (v << 1) | ((r->p[r->pos >> 3] >> (7 - (r->pos & 7))) & 1);
-        r->pos++;
+    if ((r->pos + n + 7) >> 3 > r->nbytes) { r->err = 1; return 0; }
+    while (n) {
+        const unsigned bitoff = (unsigned)(r->pos & 7), room = 8 - bitoff;
+        const unsigned take = n < room ? n : room;
+        const unsigned byte = r->p[r->pos >> 3];
+        v = (v << take) | ((byte >> (room - take)) & ((1u << take) - 1u));
+        r->pos += take;
+        n -= take;
     }
     return v;
 }
@@ -761,10 +769,15 @@ static uint32_t br_unary(bitr_t *r) {
     uint32_t q = 0;
     while (1) {
         if ((r->pos >> 3) >= r->nbytes) { r->err = 1; return 0; }
-        int bit = (r->p[r->pos >> 3] >> (7 - (r->pos & 7))) & 1;
-        r->pos++;
-        if (bit) return q;
-        q++;
+        const unsigned bitoff = (unsigned)(r->pos & 7);
+        const unsigned rest = (unsigned)(r->p[r->pos >> 3] << bitoff) & 0xffu; /* remaining bits, left aligned */
+        if (rest) {
+            const unsigned z = (unsigned)__builtin_clz(rest) - 24u;
+            r->pos += z + 1;
+            return q + z;
+        }
+        q += 8 - bitoff;
+        r->pos += 8 - bitoff;
     }
 }
 
@@ -999,6 +1012,14 @@ void oracle_int32_to_float32(const int32_t *input, int64_t n_stream, int64_t str
             output[is * stream_size + i] = offsets[is] + prod;            /* utils.c:364 */
         }
     }
+}
+
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
 }
 
 int oracle_num_threads(void) {

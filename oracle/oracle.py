@@ -56,6 +56,8 @@ def lib():
         L.oracle_det_log2.argtypes = [ctypes.c_double]
         L.oracle_det_log2.restype = ctypes.c_double
         L.oracle_num_threads.restype = ctypes.c_int
+        L.oracle_set_threads.argtypes = [ctypes.c_int]
+        L.oracle_set_threads.restype = None
         _LIB = L
     return _LIB
 
