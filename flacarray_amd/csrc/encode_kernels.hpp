@@ -1010,23 +1010,48 @@ __global__ __launch_bounds__(256) void compact_frames_kernel(const uint8_t* __re
         const uint8_t* srcb = reinterpret_cast<const uint8_t*>(srcw);
         uint8_t* dst = out + starts[s] + hb + frame_off[g];
         const uint32_t L = n - 2;  // bytes covered by the CRC
-        // ---- CRC-16 over src bytes [0, L) ----
+        // destination-aligned words: dst word w holds source bytes [hcopy + 4w, hcopy + 4w + 4)
+        const uint32_t head = (uint32_t)((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3);
+        const uint32_t hcopy = head < n ? head : n;
+        const uint32_t nw = (n - hcopy) >> 2;
+        uint32_t* dstw = reinterpret_cast<uint32_t*>(dst + hcopy);
+        const uint32_t sh = hcopy & 3;
+        // ---- one pass: CRC-16 over source bytes [0, L) and the copy of every full destination word
+        //      that does not contain a CRC byte; four 256-byte blocks in flight per iteration ----
         const uint32_t NB = (L + 255) >> 8;
         uint16_t t = 0;
         uint32_t last_full = 0;  // number of blocks in which this lane held a full word
         uint16_t partial = 0;
-        for (uint32_t b = 0; b < NB; ++b) {
-            const uint32_t o = 256u * b + 4u * (uint32_t)lane;
-            if (o + 4 <= L) {
-                const uint32_t w = srcw[o >> 2];  // little-endian load: byte o is the low byte
-                const uint16_t adv = (uint16_t)(tab[1024 + (t >> 8)] ^ tab[1280 + (t & 255)]);
-                const uint16_t c = (uint16_t)(tab[w & 255] ^ tab[256 + ((w >> 8) & 255)] ^ tab[512 + ((w >> 16) & 255)] ^ tab[768 + (w >> 24)]);
-                t = (uint16_t)(adv ^ c);
-                last_full = b + 1;
-            } else if (o < L) {
-                uint16_t c = 0;
-                for (uint32_t i = o; i < L; ++i) c = crc16_byte(c, srcb[i]);
-                partial = c;
+        for (uint32_t b0 = 0; b0 < NB; b0 += 4) {
+            uint32_t w[4], w1[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t wi = 64u * (b0 + i) + (uint32_t)lane;  // source word index (slot has slack)
+                w[i] = srcw[wi];
+                w1[i] = srcw[wi + 1];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t b = b0 + i;
+                const uint32_t o = 256u * b + 4u * (uint32_t)lane;
+                if (b < NB) {
+                    if (o + 4 <= L) {
+                        const uint16_t adv = (uint16_t)(tab[1024 + (t >> 8)] ^ tab[1280 + (t & 255)]);
+                        const uint16_t c = (uint16_t)(tab[w[i] & 255] ^ tab[256 + ((w[i] >> 8) & 255)] ^ tab[512 + ((w[i] >> 16) & 255)] ^ tab[768 + (w[i] >> 24)]);
+                        t = (uint16_t)(adv ^ c);
+                        last_full = b + 1;
+                    } else if (o < L) {
+                        uint16_t c = 0;
+                        for (uint32_t k = o; k < L; ++k) c = crc16_byte(c, (uint8_t)(w[i] >> (8 * (k - o))));
+                        partial = c;
+                    }
+                }
+                // destination word that starts at source byte o + sh (needs o >= hcopy - sh, i.e. not before the head)
+                const uint32_t so = o + sh;  // source byte offset of this destination word
+                if (so >= hcopy && so + 4 <= L) {
+                    const uint32_t v = sh ? __builtin_amdgcn_alignbyte(w1[i], w[i], sh) : w[i];
+                    dstw[(so - hcopy) >> 2] = v;
+                }
             }
         }
         uint16_t contrib = partial;
@@ -1038,47 +1063,26 @@ __global__ __launch_bounds__(256) void compact_frames_kernel(const uint8_t* __re
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) cr ^= (uint32_t)__shfl_xor((int)cr, off, 64);
         const uint16_t crc = (uint16_t)cr;
-        // ---- byte-shifted copy: destination-aligned words ----
-        const uint32_t head = (uint32_t)((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3);
-        const uint32_t hcopy = head < n ? head : n;
+        // ---- edges: head bytes, the words around the CRC, tail bytes ----
         if ((uint32_t)lane < hcopy) {
             uint8_t v = srcb[lane];
             if ((uint32_t)lane == n - 2) v = (uint8_t)(crc >> 8);
             if ((uint32_t)lane == n - 1) v = (uint8_t)crc;
             dst[lane] = v;
         }
-        const uint32_t nw = (n - hcopy) >> 2;
-        uint32_t* dstw = reinterpret_cast<uint32_t*>(dst + hcopy);
-        const uint32_t sh = hcopy & 3;  // source misalignment of every destination word
-        for (uint32_t w0 = 0; w0 < nw; w0 += 64) {
-            const uint32_t w = w0 + lane;
-            if (w < nw) {
-                const uint32_t o = hcopy + 4 * w;  // source byte offset
-                const uint32_t a0 = srcw[o >> 2];
-                uint32_t v = a0;
-                if (sh) {
-                    const uint32_t a1 = srcw[(o >> 2) + 1];
-                    v = __builtin_amdgcn_alignbyte(a1, a0, sh);
-                }
-                // patch CRC bytes that fall inside this word
-                if (o + 4 > n - 2) {
-                    for (uint32_t i = 0; i < 4; ++i) {
-                        const uint32_t bo = o + i;
-                        if (bo == n - 2) v = (v & ~(0xffu << (8 * i))) | ((uint32_t)(crc >> 8) << (8 * i));
-                        if (bo == n - 1) v = (v & ~(0xffu << (8 * i))) | ((uint32_t)(crc & 0xff) << (8 * i));
-                    }
-                }
-                dstw[w] = v;
-            }
-        }
-        const uint32_t tail0 = hcopy + 4 * nw;
-        if (tail0 + (uint32_t)lane < n) {
-            const uint32_t bo = tail0 + lane;
+        // bytes from the first destination word that was not written above to the end of the frame
+        uint32_t done = hcopy;  // first source byte not yet copied
+        if (L >= hcopy + 4) done = hcopy + (((L - hcopy) >> 2) << 2);
+        // the loop above wrote dst words with so + 4 <= L  <=>  (so - hcopy) / 4 < (L - hcopy) / 4 (so = hcopy + 4k)
+        const uint32_t rest = n - done;  // < 8 + 2
+        if ((uint32_t)lane < rest) {
+            const uint32_t bo = done + lane;
             uint8_t v = srcb[bo];
             if (bo == n - 2) v = (uint8_t)(crc >> 8);
             if (bo == n - 1) v = (uint8_t)crc;
             dst[bo] = v;
         }
+        (void)nw;
     }
 }
 
