@@ -472,6 +472,47 @@ __device__ __noinline__ BitsRet slow_unary(const uint8_t* cbase, const uint8_t* 
     return r;
 }
 
+// make chunks [chunk(bitpos), chunk(bitpos)+1] resident (synchronous loads; rare)
+__device__ __forceinline__ uint32_t ring_ensure(const uint8_t* cbase, const uint8_t* lim16, uint32_t* ring, uint32_t bitpos,
+                                                uint32_t next_chunk) {
+    while ((bitpos >> 9) + 1 >= next_chunk) { ring_load_chunk(cbase, lim16, ring, next_chunk); next_chunk++; }
+    return next_chunk;
+}
+struct ParamRet {
+    uint32_t k, escw, bitpos, next_chunk;
+};
+// partition header: Rice parameter (plen bits), escape width if k == esc (escw = 0xffffffff: none)
+__device__ __noinline__ ParamRet slow_param(const uint8_t* cbase, const uint8_t* lim16, uint32_t* ring, uint32_t bitpos,
+                                            uint32_t next_chunk, int plen, int esc) {
+    ParamRet o;
+    BitsRet r = slow_get(cbase, lim16, ring, bitpos, next_chunk, plen);
+    o.k = r.val;
+    o.escw = 0xffffffffu;
+    if ((int)r.val == esc) {
+        r = slow_get(cbase, lim16, ring, r.bitpos, r.next_chunk, 5);
+        o.escw = r.val;
+    }
+    o.bitpos = r.bitpos;
+    o.next_chunk = ring_ensure(cbase, lim16, ring, r.bitpos, r.next_chunk);
+    return o;
+}
+// one residual that the fast path cannot take: escaped (escw > 0) or a Rice code longer than 32 bits
+__device__ __noinline__ BitsRet slow_sample(const uint8_t* cbase, const uint8_t* lim16, uint32_t* ring, uint32_t bitpos,
+                                            uint32_t next_chunk, int k, int escw) {
+    BitsRet r;
+    if (escw > 0) {
+        r = slow_get(cbase, lim16, ring, bitpos, next_chunk, escw);
+        r.val = (uint32_t)((int32_t)(r.val << (32 - escw)) >> (32 - escw));
+    } else {
+        const BitsRet q = slow_unary(cbase, lim16, ring, bitpos, next_chunk);
+        r = slow_get(cbase, lim16, ring, q.bitpos, q.next_chunk, k);
+        const uint32_t uu = (q.val << k) | r.val;
+        r.val = (uint32_t)((int32_t)(uu >> 1) ^ -(int32_t)(uu & 1));
+    }
+    r.next_chunk = ring_ensure(cbase, lim16, ring, r.bitpos, r.next_chunk);
+    return r;
+}
+
 #define FA_GET(n) ({ const BitsRet r_ = slow_get(cbase, lim16, ring, bitpos, next_chunk, (n)); bitpos = r_.bitpos; next_chunk = r_.next_chunk; r_.val; })
 #define FA_GETS(n) ({ const int n_ = (n); const uint32_t v_ = FA_GET(n_); (n_ == 0) ? 0 : ((int32_t)(v_ << (32 - n_)) >> (32 - n_)); })
 #define FA_UNARY() ({ const BitsRet r_ = slow_unary(cbase, lim16, ring, bitpos, next_chunk); bitpos = r_.bitpos; next_chunk = r_.next_chunk; r_.val; })
@@ -705,19 +746,20 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
             if (i >= bs) { escw = 0; kf = 64; pleft = 0x7fffffff; }  // frame finished: consume nothing more
         }
         if (live) {
-            if (pleft <= 0) {
-                k = (int)FA_GET(plen);
-                escw = -1;
-                if (k == esc) escw = (int)FA_GET(5);
+            if (__builtin_expect(pleft <= 0, 0)) {
+                const ParamRet pr = slow_param(cbase, lim16, ring, bitpos, next_chunk, plen, esc);
+                k = (int)pr.k;
+                escw = (int)pr.escw;  // -1: plain Rice partition
                 kf = (escw < 0) ? k : 64;
+                bitpos = pr.bitpos;
+                next_chunk = pr.next_chunk;
                 pleft += ps;
-                topup();  // a slow read may leave less than 64 resident bytes ahead
             }
             int32_t r;
             uint32_t A, Bw;
             ring_window(ring, bitpos, A, Bw);
             const int z = __clz((int)A);  // 32 when A == 0
-            if (z + kf < 32) {
+            if (__builtin_expect(z + kf < 32, 1)) {
                 // fast path: the whole code (z zeros, stop bit, k low bits) lies inside A
                 const uint64_t t = ((((uint64_t)A) << 32) | Bw) << (z + 1);
                 const uint32_t low = k ? ((uint32_t)(t >> 32) >> (32 - k)) : 0u;
@@ -726,14 +768,11 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
                 bitpos += (uint32_t)(z + 1 + k);
             } else if (escw == 0) {
                 r = 0;
-            } else if (escw > 0) {
-                r = FA_GETS(escw);
-                topup();
             } else {
-                const uint32_t q = FA_UNARY();
-                const uint32_t uu = (q << k) | FA_GET(k);
-                r = (int32_t)(uu >> 1) ^ -(int32_t)(uu & 1);
-                topup();
+                const BitsRet sr = slow_sample(cbase, lim16, ring, bitpos, next_chunk, k, escw);
+                r = (int32_t)sr.val;
+                bitpos = sr.bitpos;
+                next_chunk = sr.next_chunk;
             }
             pleft--;
             double sum = 0.0;
