@@ -423,7 +423,10 @@ __device__ __forceinline__ void chunk_store(uint32_t* ring, uint32_t ci, const C
 __device__ __forceinline__ void ring_window(const uint32_t* ring, uint32_t bitpos, uint32_t& A, uint32_t& B) {
     const uint32_t wi = (bitpos >> 5) & 31;
     const uint32_t off = bitpos & 31;
-    const uint32_t w0 = ring[wi], w1 = ring[wi + 1], w2 = ring[wi + 2];
+    uint32_t w0 = ring[wi], w1 = ring[wi + 1], w2 = ring[wi + 2];
+    // keep the three reads together (one LDS round trip): without this the compiler sinks the
+    // third read into the fast-path block, behind a second wait
+    asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2));
     A = (uint32_t)((((((uint64_t)w0) << 32) | w1) << off) >> 32);
     B = (uint32_t)((((((uint64_t)w1) << 32) | w2) << off) >> 32);
 }

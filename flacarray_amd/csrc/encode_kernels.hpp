@@ -184,6 +184,86 @@ __device__ __forceinline__ void ring_put(uint32_t* ring, uint32_t pos, uint32_t 
     if (lo) atomicOr(&ring[(w + 1) & kRingMask], lo);
 }
 
+// inclusive prefix sum of a u64 across the wave (row_shr scans + row broadcasts, per 32-bit half
+// with carry handled by doing the scan on the two halves of an exact double is not possible for
+// u64, so the 64-bit add is explicit)
+__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v) {
+#define FA_SCAN_STEP(CTRL, RM, BC)                                                                         \
+    {                                                                                                      \
+        const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, RM, 0xF, BC);        \
+        const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, RM, 0xF, BC); \
+        v += ((uint64_t)hi_ << 32) | lo_;                                                                  \
+    }
+    FA_SCAN_STEP(0x111, 0xF, true)
+    FA_SCAN_STEP(0x112, 0xF, true)
+    FA_SCAN_STEP(0x114, 0xF, true)
+    FA_SCAN_STEP(0x118, 0xF, true)
+    FA_SCAN_STEP(0x142, 0xA, false)
+    FA_SCAN_STEP(0x143, 0xC, false)
+#undef FA_SCAN_STEP
+    return v;
+}
+__device__ __forceinline__ uint64_t gather_u64(uint64_t v, int src_lane) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Rice partition-order search, every order of [po_lo, po_hi] evaluated at once: lane L of the
+// layout holds partition p of order po (order po occupies 2^po lanes from 2^(po_hi+1)-2^(po+1)).
+// T = inclusive prefix sum over lanes of the per-chunk magnitude sums.  Updates the running best
+// (oracle rule: orders from high to low, strictly smaller wins) and the per-partition parameter.
+__device__ __forceinline__ void rice_search_batch(uint64_t T, int bs, int pred_order, int po_hi, int po_lo, int lane,
+                                                  bool* have, uint64_t* best, int* best_po, int* kbest) {
+    const int M = (2 << po_hi) - 1;
+    const int Lp = M - lane;                        // >= 1 for lanes that hold a slot
+    const int po = (Lp >= 1) ? (31 - __clz(Lp)) : 0;
+    const bool slot = (Lp >= 1) && (po >= po_lo);
+    const int p = lane - (M + 1 - (2 << po));
+    const uint32_t psz = (uint32_t)(bs >> po);
+    // chunk lanes covered by the partition: [p*lpp, (p+1)*lpp); order 0 covers the whole frame
+    const int lpp = (po == 0) ? 64 : (int)(psz / kChunk);
+    int hi_l = (p + 1) * lpp - 1, lo_l = p * lpp - 1;
+    hi_l = hi_l > 63 ? 63 : (hi_l < 0 ? 0 : hi_l);
+    const uint64_t Th = gather_u64(T, hi_l);
+    const uint64_t Tl = gather_u64(T, lo_l < 0 ? 0 : (lo_l > 63 ? 63 : lo_l));
+    const uint64_t S = slot ? (Th - ((lo_l >= 0) ? Tl : 0)) : 0;
+    uint64_t pb = 0;
+    int k = 0;
+    if (slot) {
+        const uint32_t n = psz - ((p == 0) ? (uint32_t)pred_order : 0u);
+        k = rice_param(S, n);
+        pb = rice_part_bits(S, n, k);
+    }
+    const uint64_t SC = wave_incl_scan_u64(pb);
+    for (int o = po_hi; o >= po_lo; --o) {
+        const int base = M + 1 - (2 << o);
+        const int end = base + (1 << o) - 1;
+        uint64_t bits = readlane_u64(SC, end) - (base > 0 ? readlane_u64(SC, base - 1) : 0) + 6;
+        if (bits > 0xffffffffULL) bits = 0xffffffffULL;
+        if (!*have || bits < *best) {
+            *have = true;
+            *best = bits;
+            *best_po = o;
+            // parameter of partition `lane` at this order lives in layout lane base + lane
+            *kbest = __builtin_amdgcn_ds_bpermute(((base + lane) & 63) << 2, k);
+        }
+    }
+}
+
+// full search for a candidate with per-chunk magnitude sums `tl` (exact, as double or u64)
+__device__ __forceinline__ uint64_t rice_search_all(uint64_t tl, int bs, int pred_order, int pmax, int lane, int* best_po,
+                                                    int* kbest) {
+    const uint64_t T = wave_incl_scan_u64(tl);
+    bool have = false;
+    uint64_t best = 0;
+    *best_po = 0;
+    *kbest = 0;
+    if (pmax >= 6) rice_search_batch(T, bs, pred_order, pmax, 6, lane, &have, &best, best_po, kbest);
+    rice_search_batch(T, bs, pred_order, pmax > 5 ? 5 : pmax, 0, lane, &have, &best, best_po, kbest);
+    return best;
+}
+
 // Rice partition-order search on the wave: lane p holds the magnitude sum of partition p at
 // order pmax.  Returns estimated bits (incl. 6 bits method+order); best order in *best_po;
 // *kbest = parameter of partition `lane` at the best order.
@@ -433,14 +513,8 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
         if (fo >= 0) {
             const double tl = (fo == 0) ? tot0 : (fo == 1) ? tot1 : (fo == 2) ? tot2 : (fo == 3) ? tot3 : tot4;
             const int pmax = max_porder_for(bs, a.max_porder, fo);
-            const int lpp = (pmax == 0) ? 64 : ((bs >> pmax) / kChunk);
-            psum[lane] = 0;
-            lds_fence();
-            if (active) atomicAdd(reinterpret_cast<unsigned long long*>(&psum[lane / lpp]), (unsigned long long)tl);
-            lds_fence();
-            const uint64_t S = psum[lane];
             const uint64_t est = 8 + (uint64_t)wasted + (uint64_t)fo * (uint64_t)bps +
-                                 rice_search_wave((lane < (1 << pmax)) ? S : 0, bs, fo, pmax, lane, &po_fix, &k_fix);
+                                 rice_search_all(active ? (uint64_t)tl : 0, bs, fo, pmax, lane, &po_fix, &k_fix);
             if (est < best_bits) {
                 best_bits = est;
                 type = 2;
@@ -575,15 +649,8 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                         lds_is_residual = true;
                         const double MX = wave_max_f64(mxr);
                         const int pmax = max_porder_for(bs, a.max_porder, lo);
-                        const int lpp = (pmax == 0) ? 64 : ((bs >> pmax) / kChunk);
-                        lds_fence();
-                        psum[lane] = 0;
-                        lds_fence();
-                        if (active) atomicAdd(reinterpret_cast<unsigned long long*>(&psum[lane / lpp]), (unsigned long long)tl);
-                        lds_fence();
-                        const uint64_t S = psum[lane];
                         int po_l = 0, k_l = 0;
-                        const uint64_t rbits = rice_search_wave((lane < (1 << pmax)) ? S : 0, bs, lo, pmax, lane, &po_l, &k_l);
+                        const uint64_t rbits = rice_search_all(active ? (uint64_t)tl : 0, bs, lo, pmax, lane, &po_l, &k_l);
                         if (MX <= 2147483647.0) {
                             const uint64_t est = 8 + (uint64_t)wasted + 4 + 5 + (uint64_t)lo * (uint64_t)(prec + bps) + rbits;
                             if (est < best_bits) {
