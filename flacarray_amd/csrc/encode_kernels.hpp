@@ -402,6 +402,9 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
     int kbest = 0;           // Rice parameter of partition `lane` for the winner
     bool lds_is_residual = false;
     int fo = -1;             // best fixed order
+    int32_t qkeep[(MLO > 0) ? MLO : 1];  // quantised LPC coefficients of the winner
+#pragma unroll
+    for (int j = 0; j < ((MLO > 0) ? MLO : 1); ++j) qkeep[j] = 0;
 
     if (is_const) {
         type = 0;
@@ -588,27 +591,53 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                     double* err = reinterpret_cast<double*>(ring + 160);        // MLO doubles
                     int32_t* qc = reinterpret_cast<int32_t*>(ring + 200);       // MLO ints
                     int* meta = reinterpret_cast<int*>(ring + 220);             // ok, lo, prec, shift
-                    if (lane == 0) {
-                        int usable = levinson<MLO>(autoc, mlo, coef, err);
-                        int prec = a.precision;
-                        int lo = best_lpc_order(err, usable, bs, bps + prec);
-                        if (bps <= 17) {
-                            int limp = 32 - bps - ilog2_u64((uint64_t)lo);
-                            if (prec > limp) prec = limp;
-                        }
-                        int sh = 0;
-                        int ok = 0;
-                        if (prec >= 2) ok = (quantize_coefs(coef + (lo - 1) * MLO, lo, prec, qc, &sh) == 0) ? 1 : 0;
-                        for (int j = lo; j < MLO; ++j) qc[j] = 0;
-                        meta[0] = ok; meta[1] = lo; meta[2] = prec; meta[3] = sh;
-                    }
+                    if (lane == 0) meta[0] = levinson<MLO>(autoc, mlo, coef, err);
                     lds_fence();
+                    const int usable = meta[0];
+                    int prec = a.precision;
+                    // order choice: lane o evaluates order o+1 (expected bits from the residual energy),
+                    // then the first strictly smaller value wins, exactly as the serial rule
+                    int lo;
+                    {
+                        double mybits = 1e300;
+                        if (lane < usable) {
+                            const double e = err[lane];
+                            const double error_scale = 0.5 / (double)bs;
+                            double bpsv;
+                            if (e > 0.0) {
+                                bpsv = 0.5 * det_log2(error_scale * e);
+                                if (!(bpsv >= 0.0)) bpsv = 0.0;
+                            } else if (e < 0.0) {
+                                bpsv = 1e32;
+                            } else {
+                                bpsv = 0.0;
+                            }
+                            mybits = bpsv * (double)(bs - (lane + 1)) + (double)((lane + 1) * (bps + prec));
+                        }
+                        double bestb = 4294967295.0;
+                        int bi = 0;
+#pragma unroll
+                        for (int o = 0; o < MLO; ++o) {
+                            const double b = readlane_f64(mybits, o);
+                            if (o < usable && b < bestb) { bestb = b; bi = o; }
+                        }
+                        lo = bi + 1;
+                    }
+                    if (bps <= 17) {
+                        const int limp = 32 - bps - ilog2_u64((uint64_t)lo);
+                        if (prec > limp) prec = limp;
+                    }
+                    int sh = 0;
+                    int32_t qreg[MLO];
+#pragma unroll
+                    for (int j = 0; j < MLO; ++j) qreg[j] = 0;
+                    int ok = 0;
+                    if (prec >= 2) ok = (quantize_coefs_t<MLO>(coef + (lo - 1) * MLO, lo, prec, qreg, &sh) == 0) ? 1 : 0;
                     FA_STAMP(6);
-                    const int ok = meta[0], lo = meta[1], prec = meta[2], sh = meta[3];
                     if (ok) {
                         double qd[MLO];
 #pragma unroll
-                        for (int j = 0; j < MLO; ++j) qd[j] = (double)qc[j];
+                        for (int j = 0; j < MLO; ++j) qd[j] = (double)qreg[j];
                         // ---- P4: LPC residual in place + magnitude sums ----------------
                         double tl = 0.0, mxr = 0.0;
                         const double scale = bitsd((uint64_t)(1023 - sh) << 52);  // 2^-sh
@@ -661,6 +690,8 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                                 kbest = k_l;
                                 shift = sh;
                                 precision = prec;
+#pragma unroll
+                                for (int j = 0; j < MLO; ++j) qkeep[j] = qreg[j];
                             }
                         }
                     }
@@ -671,15 +702,6 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
     }
 
     FA_STAMP(8);
-    // LPC coefficients must survive the ring being recycled: keep them in registers
-    int32_t qkeep[(MLO > 0) ? MLO : 1];
-    if constexpr (MLO > 0) {
-        const int32_t* qc = reinterpret_cast<const int32_t*>(ring + 200);
-#pragma unroll
-        for (int j = 0; j < MLO; ++j) qkeep[j] = (type == 3) ? qc[j] : 0;
-    }
-    lds_fence();
-
     // ---- emit (with one possible VERBATIM retry) ---------------------------------------
     uint8_t* slot = a.slots + (size_t)g * kSlotBytes;
     uint32_t total_bytes = 0;
@@ -870,7 +892,8 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int gi = gb + e;
-                    const bool valid = (gi >= order) && (gi < bs);
+                    // rows after the first of a full frame hold only residuals (order <= 32 < 256)
+                    const bool valid = (full && j > 0) ? true : ((gi >= order) && (gi < bs));
                     const uint32_t u = ((uint32_t)rs[e] << 1) ^ (uint32_t)(rs[e] >> 31);
                     const uint32_t q = u >> k;
                     const uint32_t val = (1u << k) | (u & ((1u << k) - 1u));

@@ -178,6 +178,44 @@ FA_HD int quantize_coefs(const float* c, int order, int precision, int32_t* q, i
     return 0;
 }
 
+// the same with the coefficient index unrolled (q stays in registers on the device); q[j] = 0 for j >= order
+template <int MLO>
+FA_HD int quantize_coefs_t(const float* c, int order, int precision, int32_t (&q)[MLO], int* shift) {
+    precision--;
+    const int32_t qmax = (1 << precision) - 1, qmin = -(1 << precision);
+    double cmax = 0.0;
+#pragma unroll
+    for (int i = 0; i < MLO; ++i) {
+        q[i] = 0;
+        if (i < order) {
+            const double d = fa_fabs((double)c[i]);
+            if (d > cmax) cmax = d;
+        }
+    }
+    if (cmax <= 0.0) return 2;
+    const int log2cmax = (int)((dbits(cmax) >> 52) & 0x7ff) - 1023;
+    int sh = precision - log2cmax - 1;
+    if (sh > 15) sh = 15;
+    else if (sh < -16) return 1;
+    const double mul = (sh >= 0) ? (double)(1 << sh) : 1.0;
+    const double div = (sh >= 0) ? 1.0 : (double)(1 << (-sh));
+    double error = 0.0;
+#pragma unroll
+    for (int i = 0; i < MLO; ++i) {
+        if (i < order) {
+            if (sh >= 0) error = error + (double)c[i] * mul;
+            else error = error + (double)c[i] / div;
+            double rq = (error >= 0.0) ? fa_floor(error + 0.5) : fa_ceil(error - 0.5);
+            if (rq > (double)qmax) rq = (double)qmax;
+            else if (rq < (double)qmin) rq = (double)qmin;
+            error = error - rq;
+            q[i] = (int32_t)rq;
+        }
+    }
+    *shift = sh < 0 ? 0 : sh;
+    return 0;
+}
+
 // largest Rice partition order for a frame: level limit, divisibility, 64-sample chunk
 // geometry, predictor order
 FA_HD int max_porder_for(int bs, int level_max, int pred_order) {
@@ -224,10 +262,16 @@ FA_HD int blocksize_code(int bs) {
     }
 }
 
+// CRC-8 (poly 0x07) one byte at a time through a 16-entry nibble table held in two constants
 FA_HD uint8_t crc8_byte(uint8_t crc, uint8_t v) {
-    crc ^= v;
-    for (int b = 0; b < 8; ++b) crc = (crc & 0x80) ? (uint8_t)((crc << 1) ^ 0x07) : (uint8_t)(crc << 1);
-    return crc;
+    uint32_t c = (uint32_t)(crc ^ v);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t i = c >> 4;
+        const uint64_t tab = (i < 8) ? 0x15121b1c090e0700ULL : 0x2d2a232431363f38ULL;
+        c = ((c << 4) & 0xFFu) ^ (uint32_t)((tab >> (8 * (i & 7))) & 0xFFu);
+    }
+    return (uint8_t)c;
 }
 FA_HD uint16_t crc16_byte(uint16_t crc, uint8_t v) {
     crc ^= (uint16_t)((uint16_t)v << 8);
