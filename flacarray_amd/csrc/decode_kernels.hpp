@@ -749,34 +749,42 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
             if (i >= bs) { escw = 0; kf = 64; pleft = 0x7fffffff; }  // frame finished: consume nothing more
         }
         if (live) {
-            if (__builtin_expect(pleft <= 0, 0)) {
-                const ParamRet pr = slow_param(cbase, lim16, ring, bitpos, next_chunk, plen, esc);
-                k = (int)pr.k;
-                escw = (int)pr.escw;  // -1: plain Rice partition
-                kf = (escw < 0) ? k : 64;
-                bitpos = pr.bitpos;
-                next_chunk = pr.next_chunk;
-                pleft += ps;
+            // rare events are tested wave-wide first, so the common case carries no exec-mask code
+            if (__builtin_expect(__any(pleft <= 0), 0)) {
+                if (pleft <= 0) {
+                    const ParamRet pr = slow_param(cbase, lim16, ring, bitpos, next_chunk, plen, esc);
+                    k = (int)pr.k;
+                    escw = (int)pr.escw;  // -1: plain Rice partition
+                    kf = (escw < 0) ? k : 64;
+                    bitpos = pr.bitpos;
+                    next_chunk = pr.next_chunk;
+                    pleft += ps;
+                }
             }
-            int32_t r;
             uint32_t A, Bw;
             ring_window(ring, bitpos, A, Bw);
             const int z = __clz((int)A);  // 32 when A == 0
-            if (__builtin_expect(z + kf < 32, 1)) {
-                // fast path: the whole code (z zeros, stop bit, k low bits) lies inside A
-                const uint64_t t = ((((uint64_t)A) << 32) | Bw) << (z + 1);
-                const uint32_t low = k ? ((uint32_t)(t >> 32) >> (32 - k)) : 0u;
-                const uint32_t uu = ((uint32_t)z << k) | low;
-                r = (int32_t)(uu >> 1) ^ -(int32_t)(uu & 1);
-                bitpos += (uint32_t)(z + 1 + k);
-            } else if (escw == 0) {
-                r = 0;
-            } else {
-                const BitsRet sr = slow_sample(cbase, lim16, ring, bitpos, next_chunk, k, escw);
-                r = (int32_t)sr.val;
-                bitpos = sr.bitpos;
-                next_chunk = sr.next_chunk;
+            const bool fastok = (z + kf < 32);
+            // fast path for every lane (harmless where it does not apply): z zeros, stop bit, k low bits
+            const uint64_t t = ((((uint64_t)A) << 32) | Bw) << ((z + 1) & 63);
+            const uint32_t low = __builtin_amdgcn_ubfe((uint32_t)(t >> 32), (uint32_t)((32 - k) & 31), (uint32_t)k);
+            const uint32_t uu = ((uint32_t)z << k) | low;
+            int32_t r = (int32_t)(uu >> 1) ^ -(int32_t)(uu & 1);
+            uint32_t nbp = bitpos + (uint32_t)(z + 1 + k);
+            if (__builtin_expect(!__all(fastok), 0)) {
+                if (!fastok) {
+                    if (escw == 0) {
+                        r = 0;
+                        nbp = bitpos;
+                    } else {
+                        const BitsRet sr = slow_sample(cbase, lim16, ring, bitpos, next_chunk, k, escw);
+                        r = (int32_t)sr.val;
+                        nbp = sr.bitpos;
+                        next_chunk = sr.next_chunk;
+                    }
+                }
             }
+            bitpos = nbp;
             pleft--;
             double sum = 0.0;
 #pragma unroll
@@ -833,8 +841,7 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
 
     const int bs_max = a.B;  // uniform loop bound (B >= every frame's blocksize)
     constexpr int MACRO = (MO > 16) ? MO : 16;
-    for (int i0 = 0; i0 < bs_max; i0 += MACRO) {
-        const bool guard = (i0 < 32) || (i0 + MACRO > bs_min);  // wave-uniform
+    auto macro_step = [&](auto guard_tag, int i0) __attribute__((always_inline)) {
         static_for<MACRO>([&](auto ut) __attribute__((always_inline)) {
             constexpr int u = decltype(ut)::value;
             const int i = i0 + u;
@@ -843,10 +850,22 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
                 // least 64 are resident after this top-up -> the sample code needs no residency test
                 topup();
             }
-            if (guard) sample(std::true_type{}, ut, i);
-            else sample(std::false_type{}, ut, i);
+            sample(guard_tag, ut, i);
             if constexpr ((u & 15) == 15) flush_tile(i & ~(kTileW - 1));
         });
+    };
+    // guarded head (warm-up zone), unguarded main part, guarded tail (frames shorter than B).
+    // The two guarded ranges share one loop so that the guarded body is instantiated once.
+    int main_lo = (32 + MACRO - 1) / MACRO * MACRO;
+    if (main_lo > bs_max) main_lo = bs_max;
+    int main_hi = (bs_min < bs_max ? bs_min : bs_max) / MACRO * MACRO;
+    if (main_hi < main_lo) main_hi = main_lo;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int g_lo = pass == 0 ? 0 : main_hi;
+        const int g_hi = pass == 0 ? main_lo : bs_max;
+        for (int i0 = g_lo; i0 < g_hi; i0 += MACRO) macro_step(std::true_type{}, i0);
+        if (pass == 0)
+            for (int i0 = main_lo; i0 < main_hi; i0 += MACRO) macro_step(std::false_type{}, i0);
     }
 }
 
