@@ -419,6 +419,11 @@ __device__ __forceinline__ void chunk_store(uint32_t* ring, uint32_t ci, const C
         if (v == 0 && (ci & 1) == 0) { ring[32] = d.x; ring[33] = d.y; }
     }
 }
+// the three ring words that hold bits [bitpos & ~31, +96)
+__device__ __forceinline__ void ring_words(const uint32_t* ring, uint32_t bitpos, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
+    const uint32_t wi = (bitpos >> 5) & 31;
+    w0 = ring[wi]; w1 = ring[wi + 1]; w2 = ring[wi + 2];
+}
 // bits [bitpos, bitpos+32) -> A and [bitpos+32, bitpos+64) -> B
 __device__ __forceinline__ void ring_window(const uint32_t* ring, uint32_t bitpos, uint32_t& A, uint32_t& B) {
     const uint32_t wi = (bitpos >> 5) & 31;
@@ -737,6 +742,8 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
             pend = chunk_fetch(cbase, lim16, pend_ci);
         }
     };
+    uint32_t pw0, pw1, pw2;  // ring words of the current bit position
+    ring_words(ring, bitpos, pw0, pw1, pw2);
     int kf = (escw < 0) ? k : 64;  // fast-path key: z + kf < 32  <=>  plain Rice code of at most 32 bits
 
     // one sample of every lane.  GUARD: lanes may be in warm-up or past their frame's end.
@@ -760,9 +767,12 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
                     next_chunk = pr.next_chunk;
                     pleft += ps;
                 }
+                ring_words(ring, bitpos, pw0, pw1, pw2);
             }
-            uint32_t A, Bw;
-            ring_window(ring, bitpos, A, Bw);
+            // window from the words prefetched at the end of the previous sample
+            const uint32_t off = bitpos & 31;
+            const uint32_t A = (uint32_t)((((((uint64_t)pw0) << 32) | pw1) << off) >> 32);
+            const uint32_t Bw = (uint32_t)((((((uint64_t)pw1) << 32) | pw2) << off) >> 32);
             const int z = __clz((int)A);  // 32 when A == 0
             const bool fastok = (z + kf < 32);
             // fast path for every lane (harmless where it does not apply): z zeros, stop bit, k low bits
@@ -785,10 +795,13 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
                 }
             }
             bitpos = nbp;
+            ring_words(ring, bitpos, pw0, pw1, pw2);  // LDS latency hides behind the prediction below
             pleft--;
+            // every term is an exact integer in double, so the order is free: the newest sample enters
+            // last and the loop-carried chain is one fma + scale + floor + add
             double sum = 0.0;
 #pragma unroll
-            for (int j = 0; j < MO; ++j) sum = __builtin_fma(c[j], h[(u + MO - 1 - j) % MO], sum);
+            for (int j = MO - 1; j >= 0; --j) sum = __builtin_fma(c[j], h[(u + MO - 1 - j) % MO], sum);
             const double xd = (double)r + fa_floor(sum * scale);
             h[u % MO] = xd;
             tile[lane * kTileStride + (u & (kTileW - 1))] = (int32_t)((uint32_t)(int32_t)xd << wasted);
