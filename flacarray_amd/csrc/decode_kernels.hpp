@@ -378,21 +378,28 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
 }
 
-constexpr int kTileW = 16;
-constexpr int kTileStride = 20;
-constexpr int kRingStride = 36;
+#ifndef FA_TILE_W
+#define FA_TILE_W 32
+#endif
+constexpr int kTileW = FA_TILE_W;                // samples per lane between two cooperative stores
+constexpr int kTileG = kTileW / 4;               // 16-byte groups per row
+constexpr int kTileSwz = 32 / kTileG;            // XOR swizzle step: 32 lanes of a store pass hit 32 banks
+constexpr int kDecRingWords = 34;  // 2 chunks of 16 words + 2 mirror words, per lane
+constexpr int kLaneStride = 64;  // word j of lane l lives at j*64 + l: the bank depends on the lane only
+
 constexpr int kFlagNeed16 = 1, kFlagNeed32 = 2;
 
 __device__ __forceinline__ void ring_load_chunk(const uint8_t* cbase, const uint8_t* lim16, uint32_t* ring, uint32_t ci) {
     const uint8_t* q = cbase + (size_t)ci * 64;
-    uint32_t* dst = ring + (ci & 1) * 16;
+    uint32_t* dst = ring + (ci & 1) * 16 * kLaneStride;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         uint4 d = make_uint4(0, 0, 0, 0);
         if (q + 16 * v + 16 <= lim16) d = *reinterpret_cast<const uint4*>(q + 16 * v);
         d.x = __builtin_bswap32(d.x); d.y = __builtin_bswap32(d.y); d.z = __builtin_bswap32(d.z); d.w = __builtin_bswap32(d.w);
-        *reinterpret_cast<uint4*>(dst + 4 * v) = d;
-        if (v == 0 && (ci & 1) == 0) { ring[32] = d.x; ring[33] = d.y; }  // mirror of words 0,1
+        dst[(4 * v + 0) * kLaneStride] = d.x; dst[(4 * v + 1) * kLaneStride] = d.y;
+        dst[(4 * v + 2) * kLaneStride] = d.z; dst[(4 * v + 3) * kLaneStride] = d.w;
+        if (v == 0 && (ci & 1) == 0) { ring[32 * kLaneStride] = d.x; ring[33 * kLaneStride] = d.y; }  // mirror of words 0,1
     }
 }
 // the same in two halves, so that the global loads can be issued one chunk ahead of their use
@@ -410,25 +417,26 @@ __device__ __forceinline__ Chunk chunk_fetch(const uint8_t* cbase, const uint8_t
     return c;
 }
 __device__ __forceinline__ void chunk_store(uint32_t* ring, uint32_t ci, const Chunk& c) {
-    uint32_t* dst = ring + (ci & 1) * 16;
+    uint32_t* dst = ring + (ci & 1) * 16 * kLaneStride;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         uint4 d = c.d[v];
         d.x = __builtin_bswap32(d.x); d.y = __builtin_bswap32(d.y); d.z = __builtin_bswap32(d.z); d.w = __builtin_bswap32(d.w);
-        *reinterpret_cast<uint4*>(dst + 4 * v) = d;
-        if (v == 0 && (ci & 1) == 0) { ring[32] = d.x; ring[33] = d.y; }
+        dst[(4 * v + 0) * kLaneStride] = d.x; dst[(4 * v + 1) * kLaneStride] = d.y;
+        dst[(4 * v + 2) * kLaneStride] = d.z; dst[(4 * v + 3) * kLaneStride] = d.w;
+        if (v == 0 && (ci & 1) == 0) { ring[32 * kLaneStride] = d.x; ring[33 * kLaneStride] = d.y; }
     }
 }
 // the three ring words that hold bits [bitpos & ~31, +96)
 __device__ __forceinline__ void ring_words(const uint32_t* ring, uint32_t bitpos, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
     const uint32_t wi = (bitpos >> 5) & 31;
-    w0 = ring[wi]; w1 = ring[wi + 1]; w2 = ring[wi + 2];
+    w0 = ring[wi * kLaneStride]; w1 = ring[(wi + 1) * kLaneStride]; w2 = ring[(wi + 2) * kLaneStride];
 }
 // bits [bitpos, bitpos+32) -> A and [bitpos+32, bitpos+64) -> B
 __device__ __forceinline__ void ring_window(const uint32_t* ring, uint32_t bitpos, uint32_t& A, uint32_t& B) {
     const uint32_t wi = (bitpos >> 5) & 31;
     const uint32_t off = bitpos & 31;
-    uint32_t w0 = ring[wi], w1 = ring[wi + 1], w2 = ring[wi + 2];
+    uint32_t w0 = ring[wi * kLaneStride], w1 = ring[(wi + 1) * kLaneStride], w2 = ring[(wi + 2) * kLaneStride];
     // keep the three reads together (one LDS round trip): without this the compiler sinks the
     // third read into the fast-path block, behind a second wait
     asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2));
@@ -529,15 +537,19 @@ __device__ __noinline__ BitsRet slow_sample(const uint8_t* cbase, const uint8_t*
 // left for a later pass (flag word); tasks with order <= MO_DONE were done by an earlier one.
 template <int MO, int MO_DONE>
 __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* flags) {
-    __shared__ __attribute__((aligned(16))) uint32_t rings[64 * kRingStride];
-    __shared__ __attribute__((aligned(16))) int32_t tile[64 * kTileStride];
+    __shared__ __attribute__((aligned(16))) uint32_t rings[kDecRingWords * kLaneStride];
+    __shared__ __attribute__((aligned(16))) int32_t tile[kTileW * kLaneStride];  // sample t of lane l at t*64 + (l ^ 8*(t>>2))
+#ifdef FA_DEC_LDS_PAD
+    __shared__ int32_t lds_pad_[FA_DEC_LDS_PAD];  // occupancy experiment
+    if (threadIdx.x == 9999) lds_pad_[blockIdx.x & 7] = 1;
+#endif
     __shared__ int64_t row_out[64];
     __shared__ int2 row_rng[64];
     __shared__ float2 row_fg[64];
     const int lane = threadIdx.x;
     const int64_t task = (int64_t)blockIdx.x * 64 + lane;
     const bool has_task = task < a.n_tasks;
-    uint32_t* const ring = rings + lane * kRingStride;
+    uint32_t* const ring = rings + lane;
 
     // ---- per-lane task setup ----
     int64_t s = 0, f = 0, sl_first = 0, sl_last = 0, out_off = 0;
@@ -656,7 +668,7 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
             // ---- warm-up samples, predictor description, residual header (serial per lane) ----
             for (int i = 0; i < order; ++i) {
                 const int32_t x = FA_GETS(bps);
-                if (i < kTileW) tile[lane * kTileStride + i] = (int32_t)((uint32_t)x << wasted);
+                if (i < kTileW) tile[i * kLaneStride + (lane ^ ((i >> 2) * kTileSwz))] = (int32_t)((uint32_t)x << wasted);
 #pragma unroll
                 for (int jj = 0; jj < MO; ++jj)
                     if (jj == (i % MO)) h[jj] = (double)x;
@@ -804,21 +816,25 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
             for (int j = MO - 1; j >= 0; --j) sum = __builtin_fma(c[j], h[(u + MO - 1 - j) % MO], sum);
             const double xd = (double)r + fa_floor(sum * scale);
             h[u % MO] = xd;
-            tile[lane * kTileStride + (u & (kTileW - 1))] = (int32_t)((uint32_t)(int32_t)xd << wasted);
+            tile[(i & (kTileW - 1)) * kLaneStride + (lane ^ (((i & (kTileW - 1)) >> 2) * kTileSwz))] = (int32_t)((uint32_t)(int32_t)xd << wasted);
         } else if constexpr (GUARD) {
             // warm-up sample 16..31 (orders above 16): its value sits in the history
-            if (i < bs && i >= kTileW) tile[lane * kTileStride + (u & (kTileW - 1))] = (int32_t)((uint32_t)(int32_t)h[u % MO] << wasted);
+            if (i < bs && i >= kTileW) tile[(i & (kTileW - 1)) * kLaneStride + (lane ^ (((i & (kTileW - 1)) >> 2) * kTileSwz))] = (int32_t)((uint32_t)(int32_t)h[u % MO] << wasted);
         }
     };
 
-    // cooperative store of the tile: 16 rows x 16 samples per pass, 16 bytes per lane
+    // cooperative store of the tile: (64 / kTileG) rows x kTileW samples per pass, 16 bytes per lane
     auto flush_tile = [&](int tbase) __attribute__((always_inline)) {
         __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int r = it * 16 + (lane >> 2);
-            const int cb = 4 * (lane & 3);
-            const int4 v = *reinterpret_cast<const int4*>(&tile[r * kTileStride + cb]);
+        constexpr int kRowsPerPass = 64 / kTileG;
+#pragma unroll 4
+        for (int it = 0; it < kTileG; ++it) {
+            const int r = it * kRowsPerPass + (lane / kTileG);
+            const int cg = lane % kTileG;
+            const int cb = 4 * cg;
+            const int rsw = r ^ (cg * kTileSwz);  // the writer's swizzle
+            const int4 v = make_int4(tile[(cb + 0) * kLaneStride + rsw], tile[(cb + 1) * kLaneStride + rsw], tile[(cb + 2) * kLaneStride + rsw],
+                                     tile[(cb + 3) * kLaneStride + rsw]);
             const int2 rg = row_rng[r];
             const int si = tbase + cb;
             if (si + 3 >= rg.x && si < rg.y) {
@@ -864,18 +880,22 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
                 topup();
             }
             sample(guard_tag, ut, i);
-            if constexpr ((u & 15) == 15) flush_tile(i & ~(kTileW - 1));
+            if constexpr ((u & 15) == 15) {
+                if ((i & (kTileW - 1)) == kTileW - 1) flush_tile(i & ~(kTileW - 1));  // uniform
+            }
         });
     };
     // guarded head (warm-up zone), unguarded main part, guarded tail (frames shorter than B).
     // The two guarded ranges share one loop so that the guarded body is instantiated once.
+    constexpr int kStep = (MACRO > kTileW) ? MACRO : kTileW;
+    const int end = (bs_max + kStep - 1) / kStep * kStep;  // the last tile is stored whole
     int main_lo = (32 + MACRO - 1) / MACRO * MACRO;
-    if (main_lo > bs_max) main_lo = bs_max;
+    if (main_lo > end) main_lo = end;
     int main_hi = (bs_min < bs_max ? bs_min : bs_max) / MACRO * MACRO;
     if (main_hi < main_lo) main_hi = main_lo;
     for (int pass = 0; pass < 2; ++pass) {
         const int g_lo = pass == 0 ? 0 : main_hi;
-        const int g_hi = pass == 0 ? main_lo : bs_max;
+        const int g_hi = pass == 0 ? main_lo : end;
         for (int i0 = g_lo; i0 < g_hi; i0 += MACRO) macro_step(std::true_type{}, i0);
         if (pass == 0)
             for (int i0 = main_lo; i0 < main_hi; i0 += MACRO) macro_step(std::false_type{}, i0);
