@@ -427,9 +427,11 @@ __device__ __forceinline__ void chunk_store(uint32_t* ring, uint32_t ci, const C
         if (v == 0 && (ci & 1) == 0) { ring[32 * kLaneStride] = d.x; ring[33 * kLaneStride] = d.y; }
     }
 }
-// the three ring words that hold bits [bitpos & ~31, +96)
+// the three ring words starting at the word that holds bit (bitpos - 1): with off' = ((bitpos-1) & 31) + 1
+// in 1..32 the window is ((w0:w1:w2) << off'), i.e. v_alignbit_b32 with a shift of 32 - off' in 0..31
+// (bitpos >= 8 always: the frame starts at least one byte after its chunk base)
 __device__ __forceinline__ void ring_words(const uint32_t* ring, uint32_t bitpos, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
-    const uint32_t wi = (bitpos >> 5) & 31;
+    const uint32_t wi = ((bitpos - 1) >> 5) & 31;
     w0 = ring[wi * kLaneStride]; w1 = ring[(wi + 1) * kLaneStride]; w2 = ring[(wi + 2) * kLaneStride];
 }
 // bits [bitpos, bitpos+32) -> A and [bitpos+32, bitpos+64) -> B
@@ -539,10 +541,6 @@ template <int MO, int MO_DONE>
 __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* flags) {
     __shared__ __attribute__((aligned(16))) uint32_t rings[kDecRingWords * kLaneStride];
     __shared__ __attribute__((aligned(16))) int32_t tile[kTileW * kLaneStride];  // sample t of lane l at t*64 + (l ^ 8*(t>>2))
-#ifdef FA_DEC_LDS_PAD
-    __shared__ int32_t lds_pad_[FA_DEC_LDS_PAD];  // occupancy experiment
-    if (threadIdx.x == 9999) lds_pad_[blockIdx.x & 7] = 1;
-#endif
     __shared__ int64_t row_out[64];
     __shared__ int2 row_rng[64];
     __shared__ float2 row_fg[64];
@@ -588,7 +586,7 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
         if (m.first_frame < 0 || at < 0) bad = true;
         else {
             const uint8_t* start = a.blob + at;
-            cbase = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(start) & ~(uintptr_t)63);
+            cbase = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(start - 1) & ~(uintptr_t)63);  // bitpos >= 8
             if (cbase < a.blob) cbase = a.blob;  // the blob base is 16-byte aligned (host side guarantees it)
             bitpos = (uint32_t)(start - cbase) * 8;
             ring_load_chunk(cbase, lim16, ring, 0);
@@ -742,6 +740,19 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
         row_fg[lane] = make_float2(og, cf);
     }
     const bool out_aligned = ((reinterpret_cast<uintptr_t>(a.out_f32 ? (const void*)a.out_f32 : (const void*)a.out_i32) & 15) == 0);
+    // a tile that lies inside every row's valid range and whose rows are 16-byte aligned in the
+    // output is stored without per-element tests (the common case: whole frames of whole streams)
+    int lo_max = lo, hi_min = hi;
+    bool row_al = out_aligned && (((out_off + (fstart - sl_first)) & 3) == 0);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o1 = __shfl_xor(lo_max, off, 64), o2 = __shfl_xor(hi_min, off, 64);
+        lo_max = o1 > lo_max ? o1 : lo_max;
+        hi_min = o2 < hi_min ? o2 : hi_min;
+    }
+    lo_max = __builtin_amdgcn_readfirstlane(lo_max);
+    hi_min = __builtin_amdgcn_readfirstlane(hi_min);
+    const bool all_al = __all(row_al);
     // chunk `pend_ci` is requested one chunk-time before it is stored into the ring
     uint32_t pend_ci = next_chunk;
     Chunk pend = chunk_fetch(cbase, lim16, pend_ci);
@@ -782,14 +793,14 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
                 ring_words(ring, bitpos, pw0, pw1, pw2);
             }
             // window from the words prefetched at the end of the previous sample
-            const uint32_t off = bitpos & 31;
-            const uint32_t A = (uint32_t)((((((uint64_t)pw0) << 32) | pw1) << off) >> 32);
-            const uint32_t Bw = (uint32_t)((((((uint64_t)pw1) << 32) | pw2) << off) >> 32);
+            const uint32_t sh = (~(bitpos - 1)) & 31;  // 32 - off'
+            const uint32_t A = __builtin_amdgcn_alignbit(pw0, pw1, sh);
+            const uint32_t Bw = __builtin_amdgcn_alignbit(pw1, pw2, sh);
             const int z = __clz((int)A);  // 32 when A == 0
             const bool fastok = (z + kf < 32);
             // fast path for every lane (harmless where it does not apply): z zeros, stop bit, k low bits
-            const uint64_t t = ((((uint64_t)A) << 32) | Bw) << ((z + 1) & 63);
-            const uint32_t low = __builtin_amdgcn_ubfe((uint32_t)(t >> 32), (uint32_t)((32 - k) & 31), (uint32_t)k);
+            const uint32_t X = __builtin_amdgcn_alignbit(A, Bw, (uint32_t)(31 - z) & 31);  // bits after the stop bit
+            const uint32_t low = __builtin_amdgcn_ubfe(X, (uint32_t)((32 - k) & 31), (uint32_t)k);
             const uint32_t uu = ((uint32_t)z << k) | low;
             int32_t r = (int32_t)(uu >> 1) ^ -(int32_t)(uu & 1);
             uint32_t nbp = bitpos + (uint32_t)(z + 1 + k);
@@ -827,6 +838,22 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
     auto flush_tile = [&](int tbase) __attribute__((always_inline)) {
         __builtin_amdgcn_wave_barrier();
         constexpr int kRowsPerPass = 64 / kTileG;
+#ifndef FA_NO_FASTFLUSH
+        if (all_al && tbase >= lo_max && tbase + kTileW <= hi_min && !a.out_f32) {
+#pragma unroll
+            for (int it = 0; it < kTileG; ++it) {
+                const int r = it * kRowsPerPass + (lane / kTileG);
+                const int cg = lane % kTileG;
+                const int cb = 4 * cg;
+                const int rsw = r ^ (cg * kTileSwz);
+                const int4 v = make_int4(tile[(cb + 0) * kLaneStride + rsw], tile[(cb + 1) * kLaneStride + rsw],
+                                         tile[(cb + 2) * kLaneStride + rsw], tile[(cb + 3) * kLaneStride + rsw]);
+                *reinterpret_cast<int4*>(a.out_i32 + row_out[r] + tbase + cb) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            return;
+        }
+#endif
 #pragma unroll 4
         for (int it = 0; it < kTileG; ++it) {
             const int r = it * kRowsPerPass + (lane / kTileG);
