@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "flac_math.hpp"
 
 namespace fa {
@@ -847,7 +849,8 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
         auto flush_blocks = [&]() __attribute__((always_inline)) {
             // no fence: DS operations of one wavefront are processed in issue order, so these
             // reads see every earlier ds_or of this wave
-            const uint32_t done = pos >> 11;
+            const uint32_t done = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pos >> 11));
+            blocks_flushed = (uint32_t)__builtin_amdgcn_readfirstlane((int)blocks_flushed);
             while (blocks_flushed < done) {
                 const uint32_t wi = (blocks_flushed * 64 + lane) & kRingMask;
                 const uint32_t wv = ring[wi];
@@ -880,7 +883,9 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
         } else if (type >= 2) {
             const uint32_t ps = (uint32_t)(bs >> porder);
             const uint32_t magic = (uint32_t)((0x100000000ULL + ps - 1) / ps);  // floor(gi/ps) = umulhi(gi, magic)
-            for (int j = 0; j < nrows; ++j) {
+            // GUARD: the row may hold warm-up samples or reach past the end of the frame
+            auto rice_row = [&](auto guard_tag, int j) __attribute__((always_inline)) -> bool {
+                constexpr bool GUARD = decltype(guard_tag)::value;
                 const int gb = kRow * j + 4 * lane;
                 const int4 rv = *reinterpret_cast<const int4*>(&smp[smp_idx(gb)]);
                 const int rs[4] = {rv.x, rv.y, rv.z, rv.w};
@@ -892,23 +897,30 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int gi = gb + e;
-                    // rows after the first of a full frame hold only residuals (order <= 32 < 256)
-                    const bool valid = (full && j > 0) ? true : ((gi >= order) && (gi < bs));
                     const uint32_t u = ((uint32_t)rs[e] << 1) ^ (uint32_t)(rs[e] >> 31);
                     const uint32_t q = u >> k;
                     const uint32_t val = (1u << k) | (u & ((1u << k) - 1u));
-                    const uint32_t pre = ((uint32_t)gi == pstart) ? (uint32_t)plen : 0u;
-                    iq[e] = valid ? (q + pre) : 0u;  // zeros before the stop bit (+ room for the parameter)
-                    ival[e] = valid ? val : 0u;
-                    ilen[e] = valid ? (q + pre + k + 1u) : 0u;
+                    if constexpr (GUARD) {
+                        const bool valid = (gi >= order) && (gi < bs);
+                        const uint32_t pre = ((uint32_t)gi == pstart) ? (uint32_t)plen : 0u;
+                        iq[e] = valid ? (q + pre) : 0u;  // zeros before the stop bit (+ room for the parameter)
+                        ival[e] = valid ? val : 0u;
+                        ilen[e] = valid ? (q + pre + k + 1u) : 0u;
+                    } else {
+                        // only the first sample of a lane's group can open a partition (64 | partition size)
+                        const uint32_t pre = (e == 0 && (uint32_t)gb == pstart) ? (uint32_t)plen : 0u;
+                        iq[e] = q + pre;
+                        ival[e] = val;
+                        ilen[e] = q + pre + k + 1u;
+                    }
                     lane_len += ilen[e];
                 }
                 const uint32_t incl = wave_incl_scan_u32(lane_len);
                 const uint32_t row_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                if (row_total > (uint32_t)kRowCapBits) { overflow = true; break; }
+                if (row_total > (uint32_t)kRowCapBits) return false;
                 uint32_t p = pos + incl - lane_len;
                 // the (at most one) partition parameter this lane owns in this row
-                {
+                if constexpr (GUARD) {
                     const uint32_t de = pstart - (uint32_t)gb;  // 0..3 if the partition starts in this lane's group
                     if (de < 4u && (int)pstart >= order && (int)pstart < bs) {
                         uint32_t pp = p;
@@ -917,6 +929,8 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                         if (de > 2) pp += ilen[2];
                         put_bits(pp, k, (uint32_t)plen);
                     }
+                } else {
+                    if ((uint32_t)gb == pstart) put_bits(p, k, (uint32_t)plen);
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -925,6 +939,15 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                 }
                 pos += row_total;
                 flush_blocks();
+                return true;
+            };
+            if (!rice_row(std::true_type{}, 0)) overflow = true;
+            if (full) {
+                for (int j = 1; j < nrows && !overflow; ++j)
+                    if (!rice_row(std::false_type{}, j)) overflow = true;
+            } else {
+                for (int j = 1; j < nrows && !overflow; ++j)
+                    if (!rice_row(std::true_type{}, j)) overflow = true;
             }
         }
         FA_STAMP(11);
