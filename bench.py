@@ -117,12 +117,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # test hooks (one-GPU box rehearsal of the multi-rank path): FA_BENCH_FORCE_DEVICE pins every
+    # rank to one device, FA_BENCH_BACKEND=gloo avoids RCCL's one-rank-per-GPU requirement
+    dev_index = int(os.environ.get("FA_BENCH_FORCE_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=dev)
+        backend = os.environ.get("FA_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
     L = _lib.lib()
 
     n_ch, n_samp = args.channels, args.samples
