@@ -427,38 +427,56 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
             int pe2 = pe1 - (hh.z - hh.y);
             int pe3 = pe2 - ((hh.z - hh.y) - (hh.y - hh.x));
             uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+            uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
             const int g0 = kChunk * lane;
-            for (int t4 = 0; t4 < 4; ++t4) {
-                uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+            // MASK: samples before index k do not count for order k; samples past the end do not count
+            auto group = [&](auto mask_tag, int t) __attribute__((always_inline)) {
+                constexpr bool MASK = decltype(mask_tag)::value;
+                const int4 xv = *reinterpret_cast<const int4*>(&smp[cbase + 4 * t]);
+                const int xs[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt) {
-                    const int t = 4 * t4 + tt;
-                    const int4 xv = *reinterpret_cast<const int4*>(&smp[cbase + 4 * t]);
-                    const int xs[4] = {xv.x, xv.y, xv.z, xv.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < 4; ++e) {
+                    const int x = xs[e];
+                    const int e1 = x - p1, e2 = e1 - pe1, e3 = e2 - pe2;
+                    const uint32_t xb = (uint32_t)x ^ BIAS;
+                    const uint32_t n0 = __usad(xb, BIAS, s0);
+                    const uint32_t n1 = __usad(xb, (uint32_t)p1 ^ BIAS, s1);
+                    const uint32_t n2 = __usad((uint32_t)e1 ^ BIAS, (uint32_t)pe1 ^ BIAS, s2);
+                    const uint32_t n3 = __usad((uint32_t)e2 ^ BIAS, (uint32_t)pe2 ^ BIAS, s3);
+                    const uint32_t n4 = __usad((uint32_t)e3 ^ BIAS, (uint32_t)pe3 ^ BIAS, s4);
+                    if constexpr (MASK) {
                         const int gi = g0 + 4 * t + e;
-                        const int x = xs[e];
-                        const int e1 = x - p1, e2 = e1 - pe1, e3 = e2 - pe2;
-                        const uint32_t n0 = __usad((uint32_t)x ^ BIAS, BIAS, s0);
-                        const uint32_t n1 = __usad((uint32_t)x ^ BIAS, (uint32_t)p1 ^ BIAS, s1);
-                        const uint32_t n2 = __usad((uint32_t)e1 ^ BIAS, (uint32_t)pe1 ^ BIAS, s2);
-                        const uint32_t n3 = __usad((uint32_t)e2 ^ BIAS, (uint32_t)pe2 ^ BIAS, s3);
-                        const uint32_t n4 = __usad((uint32_t)e3 ^ BIAS, (uint32_t)pe3 ^ BIAS, s4);
-                        if (full && t > 0) {
-                            s0 = n0; s1 = n1; s2 = n2; s3 = n3; s4 = n4;
-                        } else {
-                            const bool v = gi < bs;
-                            s0 = v ? n0 : s0;
-                            s1 = (v && gi >= 1) ? n1 : s1;
-                            s2 = (v && gi >= 2) ? n2 : s2;
-                            s3 = (v && gi >= 3) ? n3 : s3;
-                            s4 = (v && gi >= 4) ? n4 : s4;
-                        }
-                        p1 = x; pe1 = e1; pe2 = e2; pe3 = e3;
+                        const bool v = gi < bs;
+                        s0 = v ? n0 : s0;
+                        s1 = (v && gi >= 1) ? n1 : s1;
+                        s2 = (v && gi >= 2) ? n2 : s2;
+                        s3 = (v && gi >= 3) ? n3 : s3;
+                        s4 = (v && gi >= 4) ? n4 : s4;
+                    } else {
+                        s0 = n0; s1 = n1; s2 = n2; s3 = n3; s4 = n4;
                     }
+                    p1 = x; pe1 = e1; pe2 = e2; pe3 = e3;
                 }
+            };
+            auto fold = [&]() __attribute__((always_inline)) {
                 a0 += s0; a1 += s1; a2 += s2; a3 += s3; a4 += s4;
+                s0 = s1 = s2 = s3 = s4 = 0;
+            };
+            group(std::true_type{}, 0);  // the only group that can hold samples 0..3 of the frame
+            if (full) {
+#pragma unroll
+                for (int t = 1; t < 4; ++t) group(std::false_type{}, t);
+                fold();
+                for (int t4 = 1; t4 < 4; ++t4) {
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) group(std::false_type{}, 4 * t4 + tt);
+                    fold();
+                }
+            } else {
+                for (int t = 1; t < 16; ++t) {
+                    group(std::true_type{}, t);
+                    if ((t & 3) == 3) fold();
+                }
             }
             tot0 = (double)a0; tot1 = (double)a1; tot2 = (double)a2; tot3 = (double)a3; tot4 = (double)a4;
         } else if (active) {
@@ -503,8 +521,11 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
         {
             const double T0 = wave_sum_butterfly(tot0), T1 = wave_sum_butterfly(tot1), T2 = wave_sum_butterfly(tot2),
                          T3 = wave_sum_butterfly(tot3), T4 = wave_sum_butterfly(tot4);
-            const double M0 = wave_max_f64(mx0), M1 = wave_max_f64(mx1), M2 = wave_max_f64(mx2), M3 = wave_max_f64(mx3),
-                         M4 = wave_max_f64(mx4);
+            double M0 = 0.0, M1 = 0.0, M2 = 0.0, M3 = 0.0, M4 = 0.0;
+            if (!narrow) {
+                M0 = wave_max_f64(mx0); M1 = wave_max_f64(mx1); M2 = wave_max_f64(mx2); M3 = wave_max_f64(mx3);
+                M4 = wave_max_f64(mx4);
+            }
             const double lim = 2147483647.0;
             double smallest = 1.8446744073709552e19;  // 2^64, above any total
             if (M0 <= lim && T0 < smallest) { fo = 0; smallest = T0; }
