@@ -384,59 +384,67 @@ __device__ __forceinline__ void static_for(F&& f) {
 constexpr int kTileW = FA_TILE_W;                // samples per lane between two cooperative stores
 constexpr int kTileG = kTileW / 4;               // 16-byte groups per row
 constexpr int kTileSwz = 32 / kTileG;            // XOR swizzle step: 32 lanes of a store pass hit 32 banks
-constexpr int kDecRingWords = 34;  // 2 chunks of 16 words + 2 mirror words, per lane
+#ifndef FA_CHUNK_BYTES
+#define FA_CHUNK_BYTES 64
+#endif
+constexpr int kChunkBytes = FA_CHUNK_BYTES;           // input is staged per lane in chunks of this size (two resident)
+constexpr int kChunkW = kChunkBytes / 4;              // words per chunk
+constexpr int kChunkShift = (kChunkBytes == 64) ? 9 : 8;  // log2(bits per chunk)
+constexpr int kRingW = 2 * kChunkW;                   // ring words without the mirror
+constexpr int kDecRingWords = kRingW + 2;             // + 2 mirror words, per lane
+constexpr int kTopup = kChunkBytes / 8;               // samples between top-ups (<= 4 bytes per fast sample)
 constexpr int kLaneStride = 64;  // word j of lane l lives at j*64 + l: the bank depends on the lane only
 
 constexpr int kFlagNeed16 = 1, kFlagNeed32 = 2;
 
 __device__ __forceinline__ void ring_load_chunk(const uint8_t* cbase, const uint8_t* lim16, uint32_t* ring, uint32_t ci) {
-    const uint8_t* q = cbase + (size_t)ci * 64;
-    uint32_t* dst = ring + (ci & 1) * 16 * kLaneStride;
+    const uint8_t* q = cbase + (size_t)ci * kChunkBytes;
+    uint32_t* dst = ring + (ci & 1) * kChunkW * kLaneStride;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < kChunkBytes / 16; ++v) {
         uint4 d = make_uint4(0, 0, 0, 0);
         if (q + 16 * v + 16 <= lim16) d = *reinterpret_cast<const uint4*>(q + 16 * v);
         d.x = __builtin_bswap32(d.x); d.y = __builtin_bswap32(d.y); d.z = __builtin_bswap32(d.z); d.w = __builtin_bswap32(d.w);
         dst[(4 * v + 0) * kLaneStride] = d.x; dst[(4 * v + 1) * kLaneStride] = d.y;
         dst[(4 * v + 2) * kLaneStride] = d.z; dst[(4 * v + 3) * kLaneStride] = d.w;
-        if (v == 0 && (ci & 1) == 0) { ring[32 * kLaneStride] = d.x; ring[33 * kLaneStride] = d.y; }  // mirror of words 0,1
+        if (v == 0 && (ci & 1) == 0) { ring[kRingW * kLaneStride] = d.x; ring[(kRingW + 1) * kLaneStride] = d.y; }  // mirror of words 0,1
     }
 }
 // the same in two halves, so that the global loads can be issued one chunk ahead of their use
 struct Chunk {
-    uint4 d[4];
+    uint4 d[kChunkBytes / 16];
 };
 __device__ __forceinline__ Chunk chunk_fetch(const uint8_t* cbase, const uint8_t* lim16, uint32_t ci) {
-    const uint8_t* q = cbase + (size_t)ci * 64;
+    const uint8_t* q = cbase + (size_t)ci * kChunkBytes;
     Chunk c;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < kChunkBytes / 16; ++v) {
         c.d[v] = make_uint4(0, 0, 0, 0);
         if (q + 16 * v + 16 <= lim16) c.d[v] = *reinterpret_cast<const uint4*>(q + 16 * v);
     }
     return c;
 }
 __device__ __forceinline__ void chunk_store(uint32_t* ring, uint32_t ci, const Chunk& c) {
-    uint32_t* dst = ring + (ci & 1) * 16 * kLaneStride;
+    uint32_t* dst = ring + (ci & 1) * kChunkW * kLaneStride;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < kChunkBytes / 16; ++v) {
         uint4 d = c.d[v];
         d.x = __builtin_bswap32(d.x); d.y = __builtin_bswap32(d.y); d.z = __builtin_bswap32(d.z); d.w = __builtin_bswap32(d.w);
         dst[(4 * v + 0) * kLaneStride] = d.x; dst[(4 * v + 1) * kLaneStride] = d.y;
         dst[(4 * v + 2) * kLaneStride] = d.z; dst[(4 * v + 3) * kLaneStride] = d.w;
-        if (v == 0 && (ci & 1) == 0) { ring[32 * kLaneStride] = d.x; ring[33 * kLaneStride] = d.y; }
+        if (v == 0 && (ci & 1) == 0) { ring[kRingW * kLaneStride] = d.x; ring[(kRingW + 1) * kLaneStride] = d.y; }
     }
 }
 // the three ring words starting at the word that holds bit (bitpos - 1): with off' = ((bitpos-1) & 31) + 1
 // in 1..32 the window is ((w0:w1:w2) << off'), i.e. v_alignbit_b32 with a shift of 32 - off' in 0..31
 // (bitpos >= 8 always: the frame starts at least one byte after its chunk base)
 __device__ __forceinline__ void ring_words(const uint32_t* ring, uint32_t bitpos, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
-    const uint32_t wi = ((bitpos - 1) >> 5) & 31;
+    const uint32_t wi = ((bitpos - 1) >> 5) & (kRingW - 1);
     w0 = ring[wi * kLaneStride]; w1 = ring[(wi + 1) * kLaneStride]; w2 = ring[(wi + 2) * kLaneStride];
 }
 // bits [bitpos, bitpos+32) -> A and [bitpos+32, bitpos+64) -> B
 __device__ __forceinline__ void ring_window(const uint32_t* ring, uint32_t bitpos, uint32_t& A, uint32_t& B) {
-    const uint32_t wi = (bitpos >> 5) & 31;
+    const uint32_t wi = (bitpos >> 5) & (kRingW - 1);
     const uint32_t off = bitpos & 31;
     uint32_t w0 = ring[wi * kLaneStride], w1 = ring[(wi + 1) * kLaneStride], w2 = ring[(wi + 2) * kLaneStride];
     // keep the three reads together (one LDS round trip): without this the compiler sinks the
@@ -455,7 +463,7 @@ __device__ __noinline__ BitsRet slow_get(const uint8_t* cbase, const uint8_t* li
     BitsRet r;
     r.val = 0;
     if (n > 0) {
-        while (((bitpos + 64) >> 9) >= next_chunk) { ring_load_chunk(cbase, lim16, ring, next_chunk); next_chunk++; }
+        while (((bitpos + 64) >> kChunkShift) >= next_chunk) { ring_load_chunk(cbase, lim16, ring, next_chunk); next_chunk++; }
         uint32_t A, B;
         ring_window(ring, bitpos, A, B);
         r.val = A >> (32 - n);
@@ -471,7 +479,7 @@ __device__ __noinline__ BitsRet slow_unary(const uint8_t* cbase, const uint8_t* 
     BitsRet r;
     uint32_t q = 0;
     for (;;) {
-        while (((bitpos + 64) >> 9) >= next_chunk) { ring_load_chunk(cbase, lim16, ring, next_chunk); next_chunk++; }
+        while (((bitpos + 64) >> kChunkShift) >= next_chunk) { ring_load_chunk(cbase, lim16, ring, next_chunk); next_chunk++; }
         uint32_t A, B;
         ring_window(ring, bitpos, A, B);
         if (A) {
@@ -493,7 +501,7 @@ __device__ __noinline__ BitsRet slow_unary(const uint8_t* cbase, const uint8_t* 
 // make chunks [chunk(bitpos), chunk(bitpos)+1] resident (synchronous loads; rare)
 __device__ __forceinline__ uint32_t ring_ensure(const uint8_t* cbase, const uint8_t* lim16, uint32_t* ring, uint32_t bitpos,
                                                 uint32_t next_chunk) {
-    while ((bitpos >> 9) + 1 >= next_chunk) { ring_load_chunk(cbase, lim16, ring, next_chunk); next_chunk++; }
+    while ((bitpos >> kChunkShift) + 1 >= next_chunk) { ring_load_chunk(cbase, lim16, ring, next_chunk); next_chunk++; }
     return next_chunk;
 }
 struct ParamRet {
@@ -537,13 +545,20 @@ __device__ __noinline__ BitsRet slow_sample(const uint8_t* cbase, const uint8_t*
 
 // MO = history depth of this variant (8, 16 or 32).  Tasks whose predictor order exceeds MO are
 // left for a later pass (flag word); tasks with order <= MO_DONE were done by an earlier one.
-template <int MO, int MO_DONE>
+// F32: dequantised float32 output (needs per-row offset / 1/gain descriptors in LDS); the int32
+// variant leaves them out, which is what lets a ninth wave fit on a CU.
+template <int MO, int MO_DONE, bool F32>
 __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* flags) {
     __shared__ __attribute__((aligned(16))) uint32_t rings[kDecRingWords * kLaneStride];
     __shared__ __attribute__((aligned(16))) int32_t tile[kTileW * kLaneStride];  // sample t of lane l at t*64 + (l ^ 8*(t>>2))
+#ifdef FA_DEC_LDS_PAD
+    __shared__ int32_t lds_pad_[FA_DEC_LDS_PAD];  // occupancy experiment
+    if (a.n_tasks == -12345) lds_pad_[threadIdx.x] = (int32_t)a.nf;
+    if (a.n_tasks == -12346) a.err[0] = lds_pad_[threadIdx.x + 1];
+#endif
     __shared__ int64_t row_out[64];
     __shared__ int2 row_rng[64];
-    __shared__ float2 row_fg[64];
+    __shared__ float2 row_fg[F32 ? 64 : 1];
     const int lane = threadIdx.x;
     const int64_t task = (int64_t)blockIdx.x * 64 + lane;
     const bool has_task = task < a.n_tasks;
@@ -586,7 +601,7 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
         if (m.first_frame < 0 || at < 0) bad = true;
         else {
             const uint8_t* start = a.blob + at;
-            cbase = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(start - 1) & ~(uintptr_t)63);  // bitpos >= 8
+            cbase = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(start - 1) & ~(uintptr_t)(kChunkBytes - 1));  // bitpos >= 8
             if (cbase < a.blob) cbase = a.blob;  // the blob base is 16-byte aligned (host side guarantees it)
             bitpos = (uint32_t)(start - cbase) * 8;
             ring_load_chunk(cbase, lim16, ring, 0);
@@ -731,7 +746,7 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
     // row descriptors for the cooperative store
     row_out[lane] = out_off + (fstart - sl_first);  // output element index of frame sample 0
     row_rng[lane] = make_int2(lo, hi);
-    if (a.out_f32) {
+    if constexpr (F32) {
         float og = 0.0f, cf = 1.0f;
         if (mode != 3) {
             og = a.offsets[s];
@@ -757,7 +772,7 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
     uint32_t pend_ci = next_chunk;
     Chunk pend = chunk_fetch(cbase, lim16, pend_ci);
     auto topup = [&]() __attribute__((always_inline)) {
-        if ((bitpos >> 9) + 1 >= next_chunk) {
+        if ((bitpos >> kChunkShift) + 1 >= next_chunk) {
             if (pend_ci == next_chunk) chunk_store(ring, next_chunk, pend);
             else ring_load_chunk(cbase, lim16, ring, next_chunk);  // a slow read overtook the prefetch
             next_chunk++;
@@ -839,7 +854,7 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
         __builtin_amdgcn_wave_barrier();
         constexpr int kRowsPerPass = 64 / kTileG;
 #ifndef FA_NO_FASTFLUSH
-        if (all_al && tbase >= lo_max && tbase + kTileW <= hi_min && !a.out_f32) {
+        if (!F32 && all_al && tbase >= lo_max && tbase + kTileW <= hi_min) {
 #pragma unroll
             for (int it = 0; it < kTileG; ++it) {
                 const int r = it * kRowsPerPass + (lane / kTileG);
@@ -867,7 +882,7 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
             if (si + 3 >= rg.x && si < rg.y) {
                 const int64_t ob = row_out[r] + si;
                 const bool fullv = (si >= rg.x) && (si + 3 < rg.y) && out_aligned && ((ob & 3) == 0);
-                if (a.out_f32) {
+                if constexpr (F32) {
                     const float2 fg = row_fg[r];
                     float4 o;
                     o.x = __fadd_rn(fg.x, __fmul_rn(fg.y, (float)v.x));  // utils.c:364
@@ -901,7 +916,7 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
         static_for<MACRO>([&](auto ut) __attribute__((always_inline)) {
             constexpr int u = decltype(ut)::value;
             const int i = i0 + u;
-            if constexpr ((u & 7) == 0) {
+            if constexpr ((u % kTopup) == 0) {
                 // all lanes together: the next 8 fast-path samples need at most 32 bytes, and at
                 // least 64 are resident after this top-up -> the sample code needs no residency test
                 topup();

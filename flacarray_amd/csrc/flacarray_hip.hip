@@ -277,13 +277,21 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
     }
     if (a.B > kMaxBlock * 16) return FA_ERROR_DECODE_INIT;
     const unsigned nblk = (unsigned)((a.n_tasks + 63) / 64);
+    const bool f32 = (d_out_f32 != nullptr);
     prof_begin(2, st);
-    hipLaunchKernelGGL((decode_frames_kernel<8, -1>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
+    if (f32) hipLaunchKernelGGL((decode_frames_kernel<8, -1, true>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
+    else hipLaunchKernelGGL((decode_frames_kernel<8, -1, false>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
     prof_end(2, st);
     FA_HIP_TRY(hipMemcpyAsync(h_err, d_err, 16, hipMemcpyDeviceToHost, st));
     FA_HIP_TRY(hipStreamSynchronize(st));
-    if (h_err[1] & kFlagNeed16) hipLaunchKernelGGL((decode_frames_kernel<16, 8>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
-    if (h_err[1] & kFlagNeed32) hipLaunchKernelGGL((decode_frames_kernel<32, 16>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
+    if (h_err[1] & kFlagNeed16) {
+        if (f32) hipLaunchKernelGGL((decode_frames_kernel<16, 8, true>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
+        else hipLaunchKernelGGL((decode_frames_kernel<16, 8, false>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
+    }
+    if (h_err[1] & kFlagNeed32) {
+        if (f32) hipLaunchKernelGGL((decode_frames_kernel<32, 16, true>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
+        else hipLaunchKernelGGL((decode_frames_kernel<32, 16, false>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
+    }
     if (h_err[1]) {
         FA_HIP_TRY(hipMemcpyAsync(h_err, d_err, 16, hipMemcpyDeviceToHost, st));
         FA_HIP_TRY(hipStreamSynchronize(st));
