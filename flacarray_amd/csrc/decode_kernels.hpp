@@ -8,8 +8,11 @@
 //
 //   K6  parse_streams_kernel      one thread per stream: metadata blocks, STREAMINFO, SEEKTABLE
 //       build_frame_table_kernel  frame byte offsets from the SEEKTABLE (one thread per frame)
-//       walk_frames_kernel        streams without a complete SEEKTABLE (e.g. written by libFLAC
-//                                 through the reference): one thread walks the stream's frames
+//       scan_sync_kernel          streams without a complete SEEKTABLE (e.g. written by libFLAC
+//       check_scan_kernel         through the reference): parallel sync-code scan, frames claim
+//                                 their table entry by frame number
+//       walk_frames_kernel        fallback for streams the scan found ambiguous: one thread
+//                                 walks the stream's frames
 //   K7  decode_frames_kernel      one LANE per frame (Rice decoding and LPC restoration are
 //                                 serial recurrences inside a frame; frames are independent),
 //                                 64 frames per wavefront, samples transposed through LDS so
@@ -28,6 +31,9 @@ namespace fa {
 constexpr int kErrDecodeInit = 1 << 13;     // flacarray.h:33 ERROR_DECODE_INIT
 constexpr int kErrDecodeProcess = 1 << 14;  // flacarray.h:34 ERROR_DECODE_PROCESS
 constexpr int kErrDecodeSeek = 1 << 18;     // flacarray.h:38 ERROR_DECODE_SEEK
+
+constexpr int64_t kFrameUnset = -2;          // frame table entry not found yet (sync scan)
+constexpr int kScanSpan = 256 * 16;          // bytes one workgroup of the sync scan covers per pass
 
 struct StreamMeta {
     int64_t first_frame;  // absolute byte offset of the first frame in the blob
@@ -79,6 +85,11 @@ __global__ __launch_bounds__(256) void parse_streams_kernel(const uint8_t* __res
         m.first_frame = starts[s] + off;
         const int64_t nf = (stream_size + m.B - 1) / m.B;
         if (m.seek_abs >= 0 && m.npoints == nf) m.flags = 1;
+        if (!(m.flags & 1)) {
+            atomicAdd(err + 2, 1);
+            const int64_t span = (nb - off + kScanSpan - 1) / kScanSpan + 1;
+            atomicMax(err + 3, (int)(span > 0x7fffffff ? 0x7fffffff : span));
+        }
     } else {
         atomicOr(err, kErrDecodeInit);
     }
@@ -94,7 +105,7 @@ __global__ __launch_bounds__(256) void build_frame_table_kernel(const uint8_t* _
     const StreamMeta m = meta[s];
     if (m.first_frame < 0) return;
     if (m.B != B) { atomicOr(err, kErrDecodeInit); return; }
-    if (!(m.flags & 1)) return;
+    if (!(m.flags & 1)) { ftab[t] = kFrameUnset; return; }
     const uint8_t* sp = blob + m.seek_abs + 18 * f;
     const uint64_t sn = load_be64(sp), off = load_be64(sp + 8);
     if (sn != (uint64_t)f * (uint64_t)B) { atomicOr(err, kErrDecodeSeek); ftab[t] = -1; return; }
@@ -254,16 +265,132 @@ __device__ __forceinline__ FrameHeader read_frame_header(BitReader& br, int si_b
     return h;
 }
 
+// ------------------------------------------------------------------------------------------
+// K6s: parallel frame location for streams without a seek table (what libFLAC writes through the
+// reference: STREAMINFO + VORBIS_COMMENT, then frames).  Every byte position that holds the
+// fixed-blocksize sync code 0xFF 0xF8 followed by a header that (a) parses, (b) has a valid CRC-8,
+// (c) is mono with the stream's block size and (d) carries a frame number n < nf claims entry n of
+// the stream's frame table with a compare-and-swap.  Every true frame claims its own entry, so a
+// false candidate can only ever collide with a true one: a collision, a missing entry or a
+// non-increasing table marks the stream "ambiguous" and only such streams are walked serially.
+// ------------------------------------------------------------------------------------------
+struct HeaderBytes {
+    int ok;
+    int bs;
+    uint64_t num;
+};
+
+// frame header from a byte range [p, p + avail) (RFC 9639 9.1); fixed blocksize, mono only
+__device__ __noinline__ HeaderBytes parse_header_bytes(const uint8_t* p, int64_t avail) {
+    HeaderBytes h;
+    h.ok = 0; h.bs = 0; h.num = 0;
+    if (avail < 6) return h;
+    if (p[0] != 0xFF || p[1] != 0xF8) return h;
+    const int bsc = p[2] >> 4, src = p[2] & 15, ch = p[3] >> 4, ssc = (p[3] >> 1) & 7;
+    if (bsc == 0 || src == 15 || ch != 0 || (p[3] & 1) || ssc == 3) return h;
+    int n = 4;
+    const uint32_t u0 = p[n++];
+    int extra = 0;
+    uint64_t num = u0;
+    if (u0 & 0x80) {
+        int mbit = 0x40;
+        while ((u0 & mbit) && extra < 7) { extra++; mbit >>= 1; }
+        if (extra == 0 || extra > 5) return h;  // a frame number has at most 31 bits (6 bytes)
+        num = u0 & (uint32_t)(mbit - 1);
+    }
+    const int need = n + extra + (bsc == 6 ? 1 : bsc == 7 ? 2 : 0) + (src == 12 ? 1 : (src == 13 || src == 14) ? 2 : 0) + 1;
+    if (need > avail) return h;
+    for (int i = 0; i < extra; ++i) {
+        const uint32_t c = p[n++];
+        if ((c & 0xC0) != 0x80) return h;
+        num = (num << 6) | (c & 0x3F);
+    }
+    int bs;
+    if (bsc == 1) bs = 192;
+    else if (bsc <= 5) bs = 576 << (bsc - 2);
+    else if (bsc == 6) { bs = (int)p[n] + 1; n += 1; }
+    else if (bsc == 7) { bs = (((int)p[n] << 8) | (int)p[n + 1]) + 1; n += 2; }
+    else bs = 256 << (bsc - 8);
+    if (src == 12) n += 1;
+    else if (src == 13 || src == 14) n += 2;
+    uint8_t c8 = 0;
+    for (int i = 0; i < n; ++i) c8 = crc8_byte(c8, p[i]);
+    if (c8 != p[n]) return h;
+    h.ok = 1; h.bs = bs; h.num = num;
+    return h;
+}
+
+// grid: x = stream, y = pass over the stream's bytes in spans of kScanSpan (grid-stride in y)
+__global__ __launch_bounds__(256) void scan_sync_kernel(const uint8_t* __restrict__ blob, int64_t blob_bytes,
+                                                        const StreamMeta* __restrict__ meta, int64_t nf, int32_t B,
+                                                        int64_t stream_size, int64_t* __restrict__ ftab,
+                                                        int* __restrict__ sflag) {
+    const int64_t s = blockIdx.x;
+    const StreamMeta m = meta[s];
+    if (m.first_frame < 0 || (m.flags & 1) || m.B != B) return;
+    const int64_t lo = m.first_frame, hi = m.end_abs;
+    const int tail_bs = (int)(stream_size - (nf - 1) * (int64_t)B);
+    // 16-byte groups on the blob's own 16-byte grid (the blob base is 16-byte aligned)
+    const int64_t g_lo = lo & ~(int64_t)15;
+    for (int64_t g = g_lo + 16 * ((int64_t)blockIdx.y * 256 + threadIdx.x); g < hi; g += (int64_t)kScanSpan * gridDim.y) {
+        uint32_t w[4];
+        if (g + 16 <= blob_bytes) {
+            const uint4 v = *reinterpret_cast<const uint4*>(blob + g);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        } else {
+            w[0] = w[1] = w[2] = w[3] = 0;
+            for (int i = 0; i < 16; ++i)
+                if (g + i < blob_bytes) w[i >> 2] |= (uint32_t)blob[g + i] << (8 * (i & 3));
+        }
+        // bytes equal to 0xFF (zero bytes of ~w; the test may flag a byte above a true hit, which
+        // the exact comparison below discards)
+        uint32_t any = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t t = ~w[j];
+            any |= (t - 0x01010101u) & ~t & 0x80808080u;
+        }
+        if (!any) continue;
+        for (int i = 0; i < 16; ++i) {
+            if (((w[i >> 2] >> (8 * (i & 3))) & 0xFFu) != 0xFFu) continue;
+            const int64_t pos = g + i;
+            if (pos < lo || pos + 6 > hi) continue;
+            if (blob[pos + 1] != 0xF8) continue;
+            const HeaderBytes h = parse_header_bytes(blob + pos, hi - pos);
+            if (!h.ok || h.num >= (uint64_t)nf) continue;
+            if (h.bs != ((h.num == (uint64_t)(nf - 1)) ? tail_bs : B)) continue;
+            const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&ftab[s * nf + (int64_t)h.num]),
+                                                     (unsigned long long)kFrameUnset, (unsigned long long)pos);
+            if (old != (unsigned long long)kFrameUnset) sflag[s] = 1;
+        }
+    }
+}
+
+// one thread per (stream, frame): the scanned table must be complete, start at the first frame
+// and increase strictly
+__global__ __launch_bounds__(256) void check_scan_kernel(const StreamMeta* __restrict__ meta, int64_t n_stream, int64_t nf, int32_t B,
+                                                         const int64_t* __restrict__ ftab, int* __restrict__ sflag) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_stream * nf) return;
+    const int64_t s = t / nf, f = t - s * nf;
+    const StreamMeta m = meta[s];
+    if (m.first_frame < 0 || (m.flags & 1) || m.B != B) return;
+    const int64_t v = ftab[t];
+    const bool bad = (v < 0) || ((f == 0) ? (v != m.first_frame) : (v <= ftab[t - 1]));
+    if (bad) sflag[s] = 1;
+}
+
 // Walk every frame of streams that carry no complete seek table.  One thread per stream; the
 // walk parses but does not reconstruct (no prediction).
 __global__ __launch_bounds__(64) void walk_frames_kernel(const uint8_t* __restrict__ blob, int64_t blob_bytes,
                                                          const StreamMeta* __restrict__ meta, int64_t n_stream, int64_t nf,
                                                          int32_t B, int64_t stream_size, int64_t* __restrict__ ftab,
-                                                         int* __restrict__ err) {
+                                                         const int* __restrict__ sflag, int* __restrict__ err) {
     const int64_t s = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (s >= n_stream) return;
     const StreamMeta m = meta[s];
     if (m.first_frame < 0 || (m.flags & 1) || m.B != B) return;
+    if (sflag && !sflag[s]) return;  // the sync scan located every frame
     int64_t at = m.first_frame;
     for (int64_t f = 0; f < nf; ++f) {
         ftab[s * nf + f] = at;

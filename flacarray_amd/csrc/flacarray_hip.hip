@@ -203,10 +203,12 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
     // ---- K6: parse stream headers ----
     void* p = nullptr;
     const size_t meta_bytes = align_up((size_t)n_stream * sizeof(StreamMeta), 256);
-    int rc = get_scratch(1, meta_bytes + 256, &p);
+    int rc = get_scratch(1, meta_bytes + 256 + (size_t)n_stream * 4, &p);
     if (rc) return rc;
     StreamMeta* d_meta = reinterpret_cast<StreamMeta*>(p);
-    int* d_err = reinterpret_cast<int*>(reinterpret_cast<char*>(p) + meta_bytes);  // [0]=err [1]=flags [2]=n_walk
+    // [0]=err [1]=variant flags [2]=streams without a seek table [3]=scan passes of the longest of them
+    int* d_err = reinterpret_cast<int*>(reinterpret_cast<char*>(p) + meta_bytes);
+    int* d_sflag = d_err + 64;  // per stream: 1 = sync scan ambiguous, walk serially
     FA_HIP_TRY(hipMemsetAsync(d_err, 0, 16, st));
     hipLaunchKernelGGL(parse_streams_kernel, dim3((unsigned)((n_stream + 255) / 256)), dim3(256), 0, st, d_bytes, d_starts,
                        d_nbytes, n_stream, stream_size, d_meta, d_err);
@@ -229,8 +231,19 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
     const int64_t nt = n_stream * nf;
     hipLaunchKernelGGL(build_frame_table_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, d_bytes, d_meta, n_stream,
                        nf, B, d_ftab, d_err);
-    hipLaunchKernelGGL(walk_frames_kernel, dim3((unsigned)((n_stream + 63) / 64)), dim3(64), 0, st, d_bytes, n_bytes, d_meta,
-                       n_stream, nf, B, stream_size, d_ftab, d_err);
+    if (h_err[2] > 0) {
+        const bool scan = (std::getenv("FLACARRAY_HIP_NO_SYNC_SCAN") == nullptr);  // diagnostic: force the serial walk
+        if (scan) {
+            FA_HIP_TRY(hipMemsetAsync(d_sflag, 0, (size_t)n_stream * 4, st));
+            const unsigned ny = (unsigned)(h_err[3] < 1 ? 1 : (h_err[3] > 65535 ? 65535 : h_err[3]));
+            hipLaunchKernelGGL(scan_sync_kernel, dim3((unsigned)n_stream, ny), dim3(256), 0, st, d_bytes, n_bytes, d_meta, nf, B,
+                               stream_size, d_ftab, d_sflag);
+            hipLaunchKernelGGL(check_scan_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, d_meta, n_stream, nf, B,
+                               d_ftab, d_sflag);
+        }
+        hipLaunchKernelGGL(walk_frames_kernel, dim3((unsigned)((n_stream + 63) / 64)), dim3(64), 0, st, d_bytes, n_bytes, d_meta,
+                           n_stream, nf, B, stream_size, d_ftab, scan ? d_sflag : (const int*)nullptr, d_err);
+    }
 
     // ---- K7 ----
     DecodeArgs a;

@@ -54,3 +54,29 @@ def oracle():
 
     O.lib()
     return O
+
+
+def strip_seektable(blob, starts, nbytes):
+    """Rewrite every stream of an encoded triple without its SEEKTABLE block (fLaC, STREAMINFO
+    marked last, frames): the metadata layout libFLAC-written streams present to the decoder's
+    frame-location logic."""
+    blob = np.asarray(blob)
+    parts, new_nb = [], []
+    for s, n in zip(np.asarray(starts).reshape(-1), np.asarray(nbytes).reshape(-1)):
+        st = blob[int(s) : int(s) + int(n)]
+        assert bytes(st[:4]) == b"fLaC" and (st[4] & 0x7F) == 0
+        off = 4
+        while True:
+            last = st[off] >> 7
+            ln = (int(st[off + 1]) << 16) | (int(st[off + 2]) << 8) | int(st[off + 3])
+            off += 4 + ln
+            if last:
+                break
+        si = st[4:42].copy()
+        si[0] = 0x80  # STREAMINFO is now the last metadata block
+        out = np.concatenate([st[:4], si, st[off:]])
+        parts.append(out)
+        new_nb.append(out.shape[0])
+    new_nb = np.array(new_nb, dtype=np.int64)
+    new_st = np.concatenate([[0], np.cumsum(new_nb)[:-1]]).astype(np.int64)
+    return np.concatenate(parts), new_st, new_nb

@@ -257,3 +257,61 @@ def test_full_size_properties(fa):
     assert torch.equal(ys, x[sel, 500000 : 500000 + 70001])
     ratio = comp.numel() / (4.0 * x.numel())
     assert 0.5 < ratio < 0.65  # c/4 of the sinusoid+noise workload (SURVEY.md 8d expects 0.55-0.6)
+
+
+@pytest.mark.parametrize("level,n", [(5, 100000), (0, 50001), (8, 4096 * 3)])
+def test_decode_without_seektable(fa, oracle, level, n):
+    """Streams without a SEEKTABLE (what libFLAC writes through the reference, compress.c:337-390)
+    take the parallel sync-code scan; full decode and slices must equal the input."""
+    import torch
+
+    from tests.conftest import strip_seektable
+
+    x = np.concatenate([sinusoid_noise_i32(19, n, seed=5), full_range_i32((3, n), seed=6)])
+    blob, st, nb = oracle.encode_i32(x, level)
+    b2, s2, n2 = strip_seektable(blob, st, nb)
+    dev = torch.device("cuda", 0)
+    tb, ts, tn = (torch.from_numpy(a).to(dev) for a in (b2, s2, n2))
+    y = fa.decode_flac_device(tb, ts, tn, n)
+    assert np.array_equal(y.cpu().numpy(), x)
+    lo, hi = n // 3, n // 3 + 5000
+    ys = fa.decode_flac_device(tb, ts, tn, n, lo, hi)
+    assert np.array_equal(ys.cpu().numpy(), x[:, lo:hi])
+    # the oracle's general decoder agrees on the rewritten streams
+    assert np.array_equal(oracle.decode_i32(b2, s2, n2, n), x)
+
+
+def _crc8(data):
+    c = 0
+    for b in data:
+        c ^= b
+        for _ in range(8):
+            c = ((c << 1) ^ 0x07) & 0xFF if c & 0x80 else (c << 1) & 0xFF
+    return c
+
+
+@pytest.mark.parametrize("fake_number", [3, 200])
+def test_false_sync_inside_verbatim_frame(fa, oracle, fake_number):
+    """A VERBATIM frame whose sample bytes spell a complete, CRC-8-valid frame header.  With a frame
+    number below the frame count the false candidate collides with the true frame and the stream
+    must fall back to the serial walk; above it, it must be ignored.  Either way the decode is exact."""
+    import torch
+
+    from tests.conftest import strip_seektable
+
+    n = 8 * 4096
+    x = full_range_i32((2, n), seed=77)  # incompressible: every frame is VERBATIM, samples byte aligned
+    num = [fake_number] if fake_number < 0x80 else [0xC0 | (fake_number >> 6), 0x80 | (fake_number & 0x3F)]
+    hdr = [0xFF, 0xF8, 0xC9, 0x0E] + num
+    hdr.append(_crc8(hdr))
+    hdr += [0] * (-len(hdr) % 4)
+    words = np.frombuffer(bytes(hdr), dtype=">i4").astype(np.int32)
+    x[1, 5 * 4096 + 100 : 5 * 4096 + 100 + len(words)] = words
+    blob, st, nb = oracle.encode_i32(x, 5)
+    info = oracle.stream_info(x[1], 5)
+    assert info[5]["type"] == 1  # VERBATIM
+    b2, s2, n2 = strip_seektable(blob, st, nb)
+    assert bytes(hdr[:6]) in bytes(b2)
+    dev = torch.device("cuda", 0)
+    y = fa.decode_flac_device(torch.from_numpy(b2).to(dev), torch.from_numpy(s2).to(dev), torch.from_numpy(n2).to(dev), n)
+    assert np.array_equal(y.cpu().numpy(), x)
