@@ -165,6 +165,22 @@ __device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
     v |= (uint32_t)xchg_i32<4>((int)v);
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) | (uint32_t)__builtin_amdgcn_readlane((int)v, 32);
 }
+__device__ __forceinline__ int wave_min_i32(int v) {
+    v = min(v, xchg_i32<0>(v));
+    v = min(v, xchg_i32<1>(v));
+    v = min(v, xchg_i32<2>(v));
+    v = min(v, xchg_i32<3>(v));
+    v = min(v, xchg_i32<4>(v));
+    return min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 32));
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+    v = max(v, xchg_i32<0>(v));
+    v = max(v, xchg_i32<1>(v));
+    v = max(v, xchg_i32<2>(v));
+    v = max(v, xchg_i32<3>(v));
+    v = max(v, xchg_i32<4>(v));
+    return max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 32));
+}
 // inclusive prefix sum across the wave (row_shr scans inside each 16-lane row, then row_bcast)
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);  // row_shr:1
@@ -361,29 +377,36 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
     for (int i = lane; i < kChunkStride; i += 64) smp[i] = 0;  // chunk -1 = zero history
     const int32_t first = src[0];
     uint32_t orv = 0;
-    uint32_t absor = 0;  // OR of x ^ (x >> 31): bounds the magnitude of every sample
-    bool alleq = true;
+    bool narrow, is_const;
     const bool full = (bs == kMaxBlock) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
     if (full) {
-        // all 16 row loads in flight at once (64 KB per CU outstanding at 8 waves)
+        // all 16 row loads in flight at once (64 KB per CU outstanding at 8 waves); the running
+        // minimum / maximum (v_min3 / v_max3: half an instruction per sample each) answer both
+        // "constant?" and "narrow?"
         int4 v[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<const int4*>(src + kRow * j + 4 * lane);
+        int mn = first, mx = first;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             orv |= (uint32_t)(v[j].x | v[j].y | v[j].z | v[j].w);
-            absor |= (uint32_t)((v[j].x ^ (v[j].x >> 31)) | (v[j].y ^ (v[j].y >> 31)) | (v[j].z ^ (v[j].z >> 31)) | (v[j].w ^ (v[j].w >> 31)));
-            alleq = alleq && (v[j].x == first) && (v[j].y == first) && (v[j].z == first) && (v[j].w == first);
+            mn = min(min(mn, v[j].x), v[j].y);
+            mn = min(min(mn, v[j].z), v[j].w);
+            mx = max(max(mx, v[j].x), v[j].y);
+            mx = max(max(mx, v[j].z), v[j].w);
             *reinterpret_cast<int4*>(&smp[smp_idx(kRow * j + 4 * lane)]) = v[j];
         }
+        mn = wave_min_i32(mn);
+        mx = wave_max_i32(mx);
+        is_const = (mn == mx);
+        narrow = (mn >= -(1 << 24)) && (mx < (1 << 24));  // every |x| <= 2^24: fixed-predictor errors fit 32-bit ints
     } else {
+        bool alleq = true;
         load_frame(src, bs, 0, smp, lane, &orv, &alleq, first);
-        absor = 0xffffffffu;  // generic path: no narrow shortcut
+        is_const = __all(alleq);
+        narrow = false;  // generic path: no narrow shortcut
     }
     orv = wave_or_u32(orv);
-    absor = wave_or_u32(absor);
-    const bool narrow = absor < (1u << 24);  // every |x| < 2^24: fixed-predictor errors fit 32-bit ints
-    const bool is_const = __all(alleq);
     const int wasted = orv ? (__ffs((int)orv) - 1) : 0;
     const int bps = 32 - wasted;
     lds_fence();
@@ -670,31 +693,50 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                             double hx[MLO];
 #pragma unroll
                             for (int j = 0; j < MLO; ++j) hx[j] = (double)smp[cbase - kChunkStride + 63 - j];
-#pragma unroll 4
-                            for (int t = 0; t < 16; ++t) {
+                            // MASK: only groups that can hold warm-up samples (the first MLO of the
+                            // frame) or reach past the end of a short frame need the per-sample test
+                            auto group = [&](auto mask_tag, int t) __attribute__((always_inline)) {
+                                constexpr bool MASK = decltype(mask_tag)::value;
                                 int4* px = reinterpret_cast<int4*>(&smp[cbase + 4 * t]);
-                                int4 xv = *px;
-                                int xs[4] = {xv.x, xv.y, xv.z, xv.w};
+                                const int4 xv = *px;
+                                const int xs[4] = {xv.x, xv.y, xv.z, xv.w};
                                 int rs[4];
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
-                                    const int gi = g0 + 4 * t + e;
                                     const double xd = (double)xs[e];
                                     double sum = 0.0;
 #pragma unroll
                                     for (int j = 0; j < MLO; ++j) sum = __builtin_fma(qd[j], hx[j], sum);
                                     const double pred = fa_floor(sum * scale);
                                     const double r = xd - pred;
-                                    const bool v = (gi < bs) && (gi >= lo);
-                                    const double ar = v ? fa_fabs(r) : 0.0;
-                                    tl += ar;
-                                    mxr = ar > mxr ? ar : mxr;
-                                    rs[e] = v ? (int)r : xs[e];
+                                    if constexpr (MASK) {
+                                        const int gi = g0 + 4 * t + e;
+                                        const bool v = (gi < bs) && (gi >= lo);
+                                        const double ar = v ? fa_fabs(r) : 0.0;
+                                        tl += ar;
+                                        mxr = ar > mxr ? ar : mxr;
+                                        rs[e] = v ? (int)r : xs[e];
+                                    } else {
+                                        const double ar = fa_fabs(r);
+                                        tl += ar;
+                                        mxr = ar > mxr ? ar : mxr;
+                                        rs[e] = (int)r;
+                                    }
 #pragma unroll
                                     for (int j = MLO - 1; j > 0; --j) hx[j] = hx[j - 1];
                                     hx[0] = xd;
                                 }
                                 *px = make_int4(rs[0], rs[1], rs[2], rs[3]);
+                            };
+                            constexpr int kWarmGroups = (MLO + 3) / 4;
+                            if (full) {
+#pragma unroll
+                                for (int t = 0; t < kWarmGroups; ++t) group(std::true_type{}, t);
+#pragma unroll 4
+                                for (int t = kWarmGroups; t < 16; ++t) group(std::false_type{}, t);
+                            } else {
+#pragma unroll 4
+                                for (int t = 0; t < 16; ++t) group(std::true_type{}, t);
                             }
                         }
                         FA_STAMP(7);
@@ -780,66 +822,65 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
 
         FA_STAMP(9);
         // ---- preamble: frame header, subframe header, warm-up, LPC fields, residual header ----
-        // Every value is wave-uniform: all lanes run the packer, lane 0 stores whole words
-        // (plain stores into the zeroed ring; the row writer ORs into the last partial word).
+        // One field (<= 32 bits) per lane, lane order = bit order; a scan of the field widths
+        // gives every lane its bit position and the fields are ORed into the zeroed ring.
+        auto put_bits = [&](uint32_t P, uint32_t val, uint32_t nb) __attribute__((always_inline)) {
+            // val has nb (1..32) significant bits; place it at absolute bit position P
+            const uint32_t off = P & 31u;
+            const uint64_t X = (uint64_t)val << (64u - nb - off);
+            const uint32_t a0 = (P >> 3) & 0x7FCu;  // byte offset of the word inside the 2 KB ring
+            const uint32_t a1 = (a0 + 4u) & 0x7FCu;
+            atomicOr(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ring) + a0), (uint32_t)(X >> 32));
+            atomicOr(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ring) + a1), (uint32_t)X);
+        };
         uint32_t pos = 0;
         {
-            uint64_t acc = 0;
-            int nacc = 0;
-            uint32_t widx = 0;
-            uint8_t c8 = 0;
-            auto put = [&](uint32_t v, int nb) {  // nb in 1..32
-                acc |= (uint64_t)v << (64 - nacc - nb);
-                nacc += nb;
-                if (nacc >= 32) {
-                    if (lane == 0) ring[widx] = (uint32_t)(acc >> 32);
-                    widx++;
-                    acc <<= 32;
-                    nacc -= 32;
-                }
-            };
-            auto put_hdr = [&](uint32_t byte) { c8 = crc8_byte(c8, (uint8_t)byte); put(byte & 0xffu, 8); };
+            // wave-uniform header bytes and their CRC-8
             const int bsc = blocksize_code(bs);
-            put_hdr(0xFF);
-            put_hdr(0xF8);
-            put_hdr((uint32_t)((bsc << 4) | 9));
-            put_hdr(0x0E);  // mono, 32 bits per sample, reserved 0
+            const uint32_t b2 = (uint32_t)((bsc << 4) | 9);
             const uint64_t fn = (uint64_t)f;
-            if (fn < 0x80) put_hdr((uint32_t)fn);
-            else if (fn < 0x800) { put_hdr(0xC0 | (uint32_t)(fn >> 6)); put_hdr(0x80 | (uint32_t)(fn & 0x3F)); }
-            else if (fn < 0x10000) { put_hdr(0xE0 | (uint32_t)(fn >> 12)); put_hdr(0x80 | (uint32_t)((fn >> 6) & 0x3F)); put_hdr(0x80 | (uint32_t)(fn & 0x3F)); }
-            else if (fn < 0x200000) { put_hdr(0xF0 | (uint32_t)(fn >> 18)); put_hdr(0x80 | (uint32_t)((fn >> 12) & 0x3F)); put_hdr(0x80 | (uint32_t)((fn >> 6) & 0x3F)); put_hdr(0x80 | (uint32_t)(fn & 0x3F)); }
-            else if (fn < 0x4000000) { put_hdr(0xF8 | (uint32_t)(fn >> 24)); put_hdr(0x80 | (uint32_t)((fn >> 18) & 0x3F)); put_hdr(0x80 | (uint32_t)((fn >> 12) & 0x3F)); put_hdr(0x80 | (uint32_t)((fn >> 6) & 0x3F)); put_hdr(0x80 | (uint32_t)(fn & 0x3F)); }
-            else { put_hdr(0xFC | (uint32_t)(fn >> 30)); put_hdr(0x80 | (uint32_t)((fn >> 24) & 0x3F)); put_hdr(0x80 | (uint32_t)((fn >> 18) & 0x3F)); put_hdr(0x80 | (uint32_t)((fn >> 12) & 0x3F)); put_hdr(0x80 | (uint32_t)((fn >> 6) & 0x3F)); put_hdr(0x80 | (uint32_t)(fn & 0x3F)); }
-            if (bsc == 6) put_hdr((uint32_t)(bs - 1));
-            else if (bsc == 7) { put_hdr((uint32_t)((bs - 1) >> 8)); put_hdr((uint32_t)((bs - 1) & 0xff)); }
-            put((uint32_t)c8, 8);
-            // subframe header
-            const int tc = (type == 0) ? 0x00 : (type == 1) ? 0x01 : (type == 2) ? (0x08 | order) : (0x20 | (order - 1));
-            put((uint32_t)((tc << 1) | (wasted ? 1 : 0)), 8);
-            if (wasted) {  // unary: wasted-1 zeros, then 1
-                for (int z = wasted - 1; z > 0;) { const int c = z > 16 ? 16 : z; put(0, c); z -= c; }
-                put(1, 1);
+            const int nbu = (fn < 0x80) ? 1 : (fn < 0x800) ? 2 : (fn < 0x10000) ? 3 : (fn < 0x200000) ? 4 : (fn < 0x4000000) ? 5 : 6;
+            uint64_t ub = fn;  // UTF-8 coded frame number, big-endian in the low nbu bytes
+            if (nbu > 1) {
+                ub = ((0xFF00u >> nbu) & 0xFFu) | (fn >> (6 * (nbu - 1)));
+                for (int i = 1; i < nbu; ++i) ub = (ub << 8) | 0x80u | ((fn >> (6 * (nbu - 1 - i))) & 0x3Fu);
             }
-            const uint32_t mask = (bps == 32) ? 0xffffffffu : ((1u << bps) - 1u);
-            if (type == 0) {
-                put((uint32_t)smp[smp_idx(0)] & mask, bps);
-            } else if (type >= 2) {
-                for (int i = 0; i < order; ++i) put((uint32_t)smp[smp_idx(i)] & mask, bps);
-                if (type == 3) {
-                    put((uint32_t)(precision - 1), 4);
-                    put((uint32_t)shift, 5);
-                    if constexpr (MLO > 0) {
+            uint8_t c8 = crc8_byte(crc8_byte(0, 0xFF), 0xF8);
+            c8 = crc8_byte(c8, (uint8_t)b2);
+            c8 = crc8_byte(c8, 0x0E);  // mono, 32 bits per sample, reserved 0
+            for (int i = nbu - 1; i >= 0; --i) c8 = crc8_byte(c8, (uint8_t)(ub >> (8 * i)));
+            if (bsc == 6) c8 = crc8_byte(c8, (uint8_t)(bs - 1));
+            else if (bsc == 7) { c8 = crc8_byte(c8, (uint8_t)((bs - 1) >> 8)); c8 = crc8_byte(c8, (uint8_t)(bs - 1)); }
+            const int tc = (type == 0) ? 0x00 : (type == 1) ? 0x01 : (type == 2) ? (0x08 | order) : (0x20 | (order - 1));
+            const uint32_t smask = (bps == 32) ? 0xffffffffu : ((1u << bps) - 1u);
+            const int nwarm = (type == 0) ? 1 : (type >= 2) ? order : 0;
+            constexpr int kWarmLanes = (MLO > 4) ? MLO : 4;
+            constexpr int kL_warm = 6, kL_lpc = kL_warm + kWarmLanes, kL_coef = kL_lpc + 1, kL_rice = kL_coef + ((MLO > 0) ? MLO : 1);
+            static_assert(kL_rice < 64, "preamble fields must fit the wave");
+            uint32_t fv = 0, fnb = 0;
+            if (lane == 0) { fv = 0xFFF80000u | (b2 << 8) | 0x0Eu; fnb = 32; }
+            else if (lane == 1) { const int n1 = nbu > 4 ? 4 : nbu; fv = (uint32_t)(ub >> (8 * (nbu - n1))); fnb = 8u * (uint32_t)n1; }
+            else if (lane == 2) { if (nbu > 4) { fnb = 8u * (uint32_t)(nbu - 4); fv = (uint32_t)ub & ((1u << fnb) - 1u); } }
+            else if (lane == 3) { if (bsc == 6) { fv = (uint32_t)(bs - 1); fnb = 8; } else if (bsc == 7) { fv = (uint32_t)(bs - 1); fnb = 16; } }
+            else if (lane == 4) { fv = ((uint32_t)c8 << 8) | (uint32_t)((tc << 1) | (wasted ? 1 : 0)); fnb = 16; }
+            else if (lane == 5) { if (wasted) { fv = 1; fnb = (uint32_t)wasted; } }  // unary: wasted-1 zeros, then 1
+            else if (lane < kL_lpc) { if (lane - kL_warm < nwarm) { fv = (uint32_t)smp[smp_idx(lane - kL_warm)] & smask; fnb = (uint32_t)bps; } }
+            else if (lane == kL_lpc) { if (type == 3) { fv = ((uint32_t)(precision - 1) << 5) | (uint32_t)shift; fnb = 9; } }
+            else if (lane < kL_rice) {
+                if constexpr (MLO > 0) {
+                    if (type == 3 && lane - kL_coef < order) {
+                        int32_t q = 0;
 #pragma unroll
-                        for (int j = 0; j < MLO; ++j)
-                            if (j < order) put((uint32_t)qkeep[j] & ((1u << precision) - 1u), precision);
+                        for (int j = 0; j < MLO; ++j) q = (lane - kL_coef == j) ? qkeep[j] : q;
+                        fv = (uint32_t)q & ((1u << precision) - 1u);
+                        fnb = (uint32_t)precision;
                     }
                 }
-                put(rice2 ? 1u : 0u, 2);
-                put((uint32_t)porder, 4);
             }
-            if (nacc > 0 && lane == 0) ring[widx] = (uint32_t)(acc >> 32);
-            pos = widx * 32 + (uint32_t)nacc;
+            else if (lane == kL_rice) { if (type >= 2) { fv = ((rice2 ? 1u : 0u) << 4) | (uint32_t)porder; fnb = 6; } }
+            const uint32_t incl = wave_incl_scan_u32(fnb);
+            if (fnb) put_bits(incl - fnb, fv, fnb);
+            pos = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
         lds_fence();
 
@@ -858,15 +899,6 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
         // frame) has length 0 and ORs zeros.
         bool overflow = false;
         uint32_t blocks_flushed = 0;
-        auto put_bits = [&](uint32_t P, uint32_t val, uint32_t nb) __attribute__((always_inline)) {
-            // val has nb (1..32) significant bits; place it at absolute bit position P
-            const uint32_t off = P & 31u;
-            const uint64_t X = (uint64_t)val << (64u - nb - off);
-            const uint32_t a0 = (P >> 3) & 0x7FCu;  // byte offset of the word inside the 2 KB ring
-            const uint32_t a1 = (a0 + 4u) & 0x7FCu;
-            atomicOr(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ring) + a0), (uint32_t)(X >> 32));
-            atomicOr(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ring) + a1), (uint32_t)X);
-        };
         auto flush_blocks = [&]() __attribute__((always_inline)) {
             // no fence: DS operations of one wavefront are processed in issue order, so these
             // reads see every earlier ds_or of this wave
