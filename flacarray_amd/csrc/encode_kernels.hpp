@@ -12,7 +12,7 @@
 //   K5  write_headers_kernel   "fLaC" + STREAMINFO + SEEKTABLE of every stream
 //       compact_frames_kernel  slot -> final blob (byte-shifted copy) + CRC-16 of each frame
 //
-// LDS image of one frame (20304 B, 8 waves per CU):
+// LDS image of one frame (20312 B, 8 waves per CU):
 //   smp   65 chunks x 68 words   chunk c holds samples [64(c-1), 64c); 4 pad words per chunk make
 //                                the lane-per-chunk ds_read_b128 conflict free; chunk 0 is zeros
 //   ring  512 words              analysis scratch, then the circular bit buffer of the writer
@@ -84,7 +84,9 @@ constexpr int kChunkStride = 68;
 constexpr int kSmpWords = 65 * kChunkStride;  // 4420
 constexpr int kRingWords = 512;
 constexpr int kRingMask = kRingWords - 1;
-constexpr int kLdsWords = kSmpWords + kRingWords + 128 + 16;  // 5076 words = 20304 B
+// ring[kRingWords] mirrors ring[0]: a code that straddles the end of the ring ORs its second word
+// there (no wrap arithmetic per code); whoever reads ring[0] merges and clears the mirror
+constexpr int kLdsWords = kSmpWords + kRingWords + 2 + 128 + 16;  // 5078 words = 20312 B (8 per CU = 162.5 KB)
 
 __device__ __forceinline__ int smp_idx(int s) { return kChunkStride * ((s >> 6) + 1) + (s & 63); }
 
@@ -269,14 +271,68 @@ __device__ __forceinline__ void rice_search_batch(uint64_t T, int bs, int pred_o
     }
 }
 
+// The same search in 32-bit arithmetic, valid when every lane's sum is below 2^24 (so the frame
+// total is below 2^30): partition sums, bit estimates (<= S + 2^17 + 4 per partition) and their
+// totals then fit 32 bits, and every value equals what the 64-bit version computes.
+__device__ __forceinline__ int rice_param_u32(uint32_t mean, uint32_t n) {
+    if (mean < 2) return 0;
+    const uint32_t fpd = 0x40000u / n;
+    const uint32_t m1 = mean - 1;
+    const uint32_t v = (__umulhi(m1, fpd) << 14) | ((m1 * fpd) >> 18);  // ((mean-1)*fpd) >> 18, below 2^32
+    return v ? (32 - __clz((int)v)) : 0;  // <= 30 here, so the Rice2 clamp never applies
+}
+__device__ __forceinline__ void rice_search_batch_u32(uint32_t T, int bs, int pred_order, int po_hi, int po_lo, int lane,
+                                                      bool* have, uint32_t* best, int* best_po, int* kbest) {
+    const int M = (2 << po_hi) - 1;
+    const int Lp = M - lane;
+    const int po = (Lp >= 1) ? (31 - __clz(Lp)) : 0;
+    const bool slot = (Lp >= 1) && (po >= po_lo);
+    const int p = lane - (M + 1 - (2 << po));
+    const uint32_t psz = (uint32_t)(bs >> po);
+    const int lpp = (po == 0) ? 64 : (int)(psz / kChunk);
+    int hi_l = (p + 1) * lpp - 1, lo_l = p * lpp - 1;
+    hi_l = hi_l > 63 ? 63 : (hi_l < 0 ? 0 : hi_l);
+    const uint32_t Th = (uint32_t)__builtin_amdgcn_ds_bpermute(hi_l << 2, (int)T);
+    const uint32_t Tl = (uint32_t)__builtin_amdgcn_ds_bpermute((lo_l < 0 ? 0 : (lo_l > 63 ? 63 : lo_l)) << 2, (int)T);
+    const uint32_t S = slot ? (Th - ((lo_l >= 0) ? Tl : 0u)) : 0u;
+    uint32_t pb = 0;
+    int k = 0;
+    if (slot) {
+        const uint32_t n = psz - ((p == 0) ? (uint32_t)pred_order : 0u);
+        k = rice_param_u32(S, n);
+        pb = 4u + (uint32_t)(1 + k) * n + (k ? (S >> (k - 1)) : (S << 1)) - (n >> 1);
+    }
+    const uint32_t SC = wave_incl_scan_u32(pb);
+    for (int o = po_hi; o >= po_lo; --o) {
+        const int base = M + 1 - (2 << o);
+        const int end = base + (1 << o) - 1;
+        const uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int)SC, end) -
+                              (base > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)SC, base - 1) : 0u) + 6u;
+        if (!*have || bits < *best) {
+            *have = true;
+            *best = bits;
+            *best_po = o;
+            *kbest = __builtin_amdgcn_ds_bpermute(((base + lane) & 63) << 2, k);
+        }
+    }
+}
+
 // full search for a candidate with per-chunk magnitude sums `tl` (exact, as double or u64)
 __device__ __forceinline__ uint64_t rice_search_all(uint64_t tl, int bs, int pred_order, int pmax, int lane, int* best_po,
                                                     int* kbest) {
+    *best_po = 0;
+    *kbest = 0;
+    if (__all(tl < (1u << 24))) {
+        const uint32_t T = wave_incl_scan_u32((uint32_t)tl);
+        bool have = false;
+        uint32_t best = 0;
+        if (pmax >= 6) rice_search_batch_u32(T, bs, pred_order, pmax, 6, lane, &have, &best, best_po, kbest);
+        rice_search_batch_u32(T, bs, pred_order, pmax > 5 ? 5 : pmax, 0, lane, &have, &best, best_po, kbest);
+        return best;
+    }
     const uint64_t T = wave_incl_scan_u64(tl);
     bool have = false;
     uint64_t best = 0;
-    *best_po = 0;
-    *kbest = 0;
     if (pmax >= 6) rice_search_batch(T, bs, pred_order, pmax, 6, lane, &have, &best, best_po, kbest);
     rice_search_batch(T, bs, pred_order, pmax > 5 ? 5 : pmax, 0, lane, &have, &best, best_po, kbest);
     return best;
@@ -359,8 +415,8 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
 #endif
     int32_t* smp = lds;
     uint32_t* ring = reinterpret_cast<uint32_t*>(lds + kSmpWords);
-    uint64_t* psum = reinterpret_cast<uint64_t*>(lds + kSmpWords + kRingWords);
-    uint8_t* kpar = reinterpret_cast<uint8_t*>(lds + kSmpWords + kRingWords + 128);
+    uint64_t* psum = reinterpret_cast<uint64_t*>(lds + kSmpWords + kRingWords + 2);
+    uint8_t* kpar = reinterpret_cast<uint8_t*>(lds + kSmpWords + kRingWords + 2 + 128);
 
     const int lane = threadIdx.x;
     const int64_t g = blockIdx.x;
@@ -814,6 +870,7 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
         // Rice parameter table and ring reset
         kpar[lane] = (uint8_t)kbest;
         for (int i = lane; i < kRingWords; i += 64) ring[i] = 0;
+        if (lane == 0) ring[kRingWords] = 0;
         lds_fence();
 
         bool rice2 = false;
@@ -829,9 +886,8 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
             const uint32_t off = P & 31u;
             const uint64_t X = (uint64_t)val << (64u - nb - off);
             const uint32_t a0 = (P >> 3) & 0x7FCu;  // byte offset of the word inside the 2 KB ring
-            const uint32_t a1 = (a0 + 4u) & 0x7FCu;
             atomicOr(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ring) + a0), (uint32_t)(X >> 32));
-            atomicOr(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ring) + a1), (uint32_t)X);
+            atomicOr(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ring) + a0 + 4), (uint32_t)X);  // may be the mirror word
         };
         uint32_t pos = 0;
         {
@@ -906,8 +962,9 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
             blocks_flushed = (uint32_t)__builtin_amdgcn_readfirstlane((int)blocks_flushed);
             while (blocks_flushed < done) {
                 const uint32_t wi = (blocks_flushed * 64 + lane) & kRingMask;
-                const uint32_t wv = ring[wi];
+                uint32_t wv = ring[wi];
                 ring[wi] = 0;
+                if ((blocks_flushed & 7u) == 0 && lane == 0) { wv |= ring[kRingWords]; ring[kRingWords] = 0; }
                 reinterpret_cast<uint32_t*>(slot)[blocks_flushed * 64 + lane] = __builtin_bswap32(wv);
                 blocks_flushed++;
             }
@@ -1021,7 +1078,11 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
         const uint32_t nwords = (total_bytes + 3) >> 2;
         for (uint32_t w0 = blocks_flushed * 64; w0 < nwords; w0 += 64) {
             const uint32_t wl = w0 + lane;
-            if (wl < nwords) reinterpret_cast<uint32_t*>(slot)[wl] = __builtin_bswap32(ring[wl & kRingMask]);
+            if (wl < nwords) {
+                uint32_t wv = ring[wl & kRingMask];
+                if ((wl & kRingMask) == 0) wv |= ring[kRingWords];
+                reinterpret_cast<uint32_t*>(slot)[wl] = __builtin_bswap32(wv);
+            }
         }
         break;
     }
