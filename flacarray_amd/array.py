@@ -372,3 +372,50 @@ class FlacArray:
             mpi_comm=None,
             mpi_dist=None,
         )
+
+    def write_hdf5(self, hgrp):
+        """Write the compressed representation to an open HDF5 group (array.py:639-682), format
+        version 1 (flacarray_amd/hdf5.py)."""
+        from .hdf5 import write_compressed
+
+        write_compressed(
+            hgrp,
+            self._leading_shape,
+            self._global_leading_shape,
+            self._stream_size,
+            self._stream_starts,
+            self._global_stream_starts,
+            self._stream_nbytes,
+            self._stream_offsets,
+            self._stream_gains,
+            self._compressed,
+            2 if self._is_int64 else 1,
+        )
+
+    @classmethod
+    def read_hdf5(cls, hgrp, keep=None, mpi_comm=None, mpi_dist=None, no_flatten=False):
+        """Construct a FlacArray from an HDF5 group (array.py:684-764).  With `keep` the array
+        holds only the selected streams, as a 2-D (n_kept, stream_size) array."""
+        from .hdf5 import read_compressed
+        from .utils import compressed_dtype
+
+        (local_shape, global_shape, compressed, n_channels, stream_starts, stream_nbytes, stream_offsets, stream_gains,
+         mpi_dist, keep_indices) = read_compressed(hgrp, keep=keep, mpi_comm=mpi_comm, mpi_dist=mpi_dist)
+        dt = compressed_dtype(n_channels, stream_offsets, stream_gains)
+        if (len(local_shape) == 2 and local_shape[0] == 1) and not no_flatten:
+            shape = (local_shape[1],)
+        else:
+            shape = local_shape
+        return FlacArray(
+            None,
+            shape=shape,
+            global_shape=shape if keep is not None else global_shape,
+            compressed=compressed,
+            dtype=dt,
+            stream_starts=stream_starts,
+            stream_nbytes=stream_nbytes,
+            stream_offsets=stream_offsets,
+            stream_gains=stream_gains,
+            mpi_comm=None,
+            mpi_dist=None,
+        )

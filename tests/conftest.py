@@ -80,3 +80,31 @@ def strip_seektable(blob, starts, nbytes):
     new_nb = np.array(new_nb, dtype=np.int64)
     new_st = np.concatenate([[0], np.cumsum(new_nb)[:-1]]).astype(np.int64)
     return np.concatenate(parts), new_st, new_nb
+
+
+class FakeH5Dataset:
+    """The slice of the h5py.Dataset API that flacarray_amd.hdf5 uses (h5py is absent from this image)."""
+
+    def __init__(self, shape, dtype):
+        self._a = np.zeros(shape, dtype=dtype)
+        self.attrs = {}
+
+    shape = property(lambda self: self._a.shape)
+    dtype = property(lambda self: self._a.dtype)
+    size = property(lambda self: self._a.size)
+
+    def __getitem__(self, k):
+        return self._a[k]
+
+    def __setitem__(self, k, v):
+        self._a[k] = v
+
+
+class FakeH5Group(dict):
+    def __init__(self):
+        super().__init__()
+        self.attrs = {}
+
+    def create_dataset(self, name, shape, dtype=None):
+        self[name] = FakeH5Dataset(shape, dtype)
+        return self[name]

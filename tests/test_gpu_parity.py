@@ -315,3 +315,37 @@ def test_false_sync_inside_verbatim_frame(fa, oracle, fake_number):
     dev = torch.device("cuda", 0)
     y = fa.decode_flac_device(torch.from_numpy(b2).to(dev), torch.from_numpy(s2).to(dev), torch.from_numpy(n2).to(dev), n)
     assert np.array_equal(y.cpu().numpy(), x)
+
+
+def test_hdf5_write_read_array(fa):
+    """hdf5.write_array / read_array and FlacArray.write_hdf5 / read_hdf5 on the version-1 layout
+    (in-memory stand-in for h5py.Group: h5py is absent from this image)."""
+    from flacarray_amd import hdf5 as H
+    from tests.conftest import FakeH5Group
+
+    x = sinusoid_noise_i32(6, 20000, seed=21).reshape(3, 2, 20000)
+    g = FakeH5Group()
+    H.write_array(x, g, level=5)
+    assert np.array_equal(H.read_array(g), x)
+    assert np.array_equal(H.read_array(g, stream_slice=slice(100, 9000)), x[..., 100:9000])
+    keep = np.array([[True, False], [False, False], [True, True]])
+    arr, idx = H.read_array(g, keep=keep, keep_indices=True)
+    assert idx == [(0, 0), (2, 0), (2, 1)] and np.array_equal(arr, x[keep])
+
+    xf = sinusoid_noise_f32(4, 10000, seed=22)
+    gf = FakeH5Group()
+    H.write_array(xf, gf, quanta=1e-4)
+    assert gf["stream_offsets"].dtype == np.float32 and gf.attrs["flac_channels"] == "1"
+    assert np.max(np.abs(H.read_array(gf) - xf)) <= 0.5e-4 + 1e-5
+
+    fl = fa.FlacArray.from_array(x)
+    g2 = FakeH5Group()
+    fl.write_hdf5(g2)
+    back = fa.FlacArray.read_hdf5(g2)
+    assert back == fl and np.array_equal(back.to_array(), x)
+    one = fa.FlacArray.from_array(x[0, 0])
+    g3 = FakeH5Group()
+    one.write_hdf5(g3)
+    assert g3["stream_starts"].shape == (1,)
+    assert fa.FlacArray.read_hdf5(g3).shape == (20000,)
+    assert fa.FlacArray.read_hdf5(g3, no_flatten=True).shape == (1, 20000)

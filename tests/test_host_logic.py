@@ -191,3 +191,40 @@ def test_array_surface_cpu_standin(cpu_backend):
 @pytest.mark.gpu
 def test_array_surface_gpu():
     _check_array_surface()
+
+
+def test_hdf5_v1_layout_roundtrip(oracle):
+    """write_compressed -> read_compressed on the reference's format-version-1 layout
+    (hdf5.py:195-245, hdf5_load_v1.py:136-157): names, dtypes, attrs, keep selection."""
+    from flacarray_amd import hdf5 as H
+    from tests.conftest import FakeH5Group, sinusoid_noise_i32
+
+    x = sinusoid_noise_i32(6, 5000, seed=3).reshape(2, 3, 5000)
+    blob, st, nb = oracle.encode_i32(x.reshape(6, 5000), 5)
+    st, nb = st.reshape(2, 3), nb.reshape(2, 3)
+    off = np.arange(6, dtype=np.float32).reshape(2, 3)
+    gain = (1.0 + np.arange(6, dtype=np.float32)).reshape(2, 3)
+    g = FakeH5Group()
+    H.write_compressed(g, (2, 3), (2, 3), 5000, st, st, nb, off, gain, blob, 1)
+    assert g.attrs["flacarray_format_version"] == "1" and g.attrs["flac_channels"] == "1"
+    assert set(g) == {"stream_starts", "stream_bytes", "stream_offsets", "stream_gains", "compressed"}
+    assert g["stream_starts"].attrs["stream_size"] == 5000 and g["stream_starts"].dtype == np.int64
+    assert g["compressed"].dtype == np.uint8 and g["compressed"].shape == (blob.shape[0],)
+
+    ls, gs, comp, nch, s2, n2, o2, g2, dist, idx = H.read_compressed(g)
+    assert ls == (2, 3, 5000) and gs == (2, 3, 5000) and nch == 1 and idx is None
+    assert np.array_equal(comp, blob) and np.array_equal(s2, st) and np.array_equal(n2, nb)
+    assert np.array_equal(o2, off) and np.array_equal(g2, gain)
+    assert np.array_equal(oracle.decode_i32(comp, s2.reshape(-1), n2.reshape(-1), 5000), x.reshape(6, 5000))
+
+    keep = np.zeros((2, 3), dtype=bool)
+    keep[0, 2] = keep[1, 1] = True
+    ls, gs, comp, nch, s2, n2, o2, g2, dist, idx = H.read_compressed(g, keep=keep)
+    assert ls == (2, 5000) and idx == [(0, 2), (1, 1)]
+    assert np.array_equal(n2, [nb[0, 2], nb[1, 1]]) and np.array_equal(s2, [0, nb[0, 2]])
+    assert np.array_equal(o2, [off[0, 2], off[1, 1]])
+    assert np.array_equal(oracle.decode_i32(comp, s2, n2, 5000), x[[0, 1], [2, 1]])
+
+    g.attrs["flacarray_format_version"] = "0"
+    with pytest.raises(RuntimeError):
+        H.read_compressed(g)
