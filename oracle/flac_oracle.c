@@ -466,23 +466,11 @@ static void put_utf8(bitw_t *w, uint64_t v) {
     else { bw_put(w, 0xFC | (v >> 30), 8); bw_put(w, 0x80 | ((v >> 24) & 0x3F), 8); bw_put(w, 0x80 | ((v >> 18) & 0x3F), 8); bw_put(w, 0x80 | ((v >> 12) & 0x3F), 8); bw_put(w, 0x80 | ((v >> 6) & 0x3F), 8); bw_put(w, 0x80 | (v & 0x3F), 8); }
 }
 
-static void encode_frame(bitw_t *w, const int32_t *xin, int bs, uint64_t frame_no, const enc_params_t *P,
-                         const float *win, oracle_frame_info *info) {
-    static __thread int32_t x[MAX_BLOCK], rfix[MAX_BLOCK], rlpc[MAX_BLOCK];
-    size_t frame_start = (size_t)(w->nbits >> 3);
-
-    /* ---- frame header (RFC 9639 9.1) ---- */
-    int bsc = blocksize_code(bs);
-    bw_put(w, 0xFFF8, 16);
-    bw_put(w, (uint64_t)bsc, 4);
-    bw_put(w, 9, 4);  /* 44.1 kHz: libFLAC default sample rate, the reference never sets one */
-    bw_put(w, 0, 4);  /* mono */
-    bw_put(w, 7, 3);  /* 32 bits per sample */
-    bw_put(w, 0, 1);
-    put_utf8(w, frame_no);
-    if (bsc == 6) bw_put(w, (uint64_t)(bs - 1), 8);
-    else if (bsc == 7) bw_put(w, (uint64_t)(bs - 1), 16);
-    bw_put(w, crc8(w->buf + frame_start, (size_t)(w->nbits >> 3) - frame_start), 8);
+/* One subframe: samples xin[0], xin[stride], ... (stride 2 picks one channel of an interleaved pair) */
+static void encode_subframe(bitw_t *w, const int32_t *xin_s, int stride, int bs, const enc_params_t *P, const float *win,
+                            oracle_frame_info *info) {
+    static __thread int32_t xin[MAX_BLOCK], x[MAX_BLOCK], rfix[MAX_BLOCK], rlpc[MAX_BLOCK];
+    for (int i = 0; i < bs; ++i) xin[i] = xin_s[(size_t)i * (size_t)stride];
 
     /* ---- wasted bits ---- */
     uint32_t orv = 0;
@@ -616,11 +604,6 @@ static void encode_frame(bitw_t *w, const int32_t *xin, int bs, uint64_t frame_n
         }
         rice_write(w, res, bs, order, &rc);
     }
-    bw_align(w);
-    bw_reserve(w, 16);
-    uint16_t c = crc16(w->buf + frame_start, (size_t)(w->nbits >> 3) - frame_start);
-    bw_put(w, c, 16);
-
     if (info) {
         info->type = type;
         info->order = (type >= 2) ? order : 0;
@@ -628,9 +611,38 @@ static void encode_frame(bitw_t *w, const int32_t *xin, int bs, uint64_t frame_n
         info->wasted = wasted;
         info->shift = (type == 3) ? shift : 0;
         info->precision = (type == 3) ? precision : 0;
-        info->nbytes = (int32_t)((w->nbits >> 3) - frame_start);
         info->blocksize = bs;
     }
+}
+
+/* One frame of nch (1 or 2) channels; xin is sample-interleaved for nch == 2 (channel 0 = the low
+ * 32 bits of the reference's int64 samples, utils.c:96-107; channels are coded independently,
+ * channel assignment 0b0001) */
+static void encode_frame(bitw_t *w, const int32_t *xin, int nch, int bs, uint64_t frame_no, const enc_params_t *P,
+                         const float *win, oracle_frame_info *info) {
+    size_t frame_start = (size_t)(w->nbits >> 3);
+
+    /* ---- frame header (RFC 9639 9.1) ---- */
+    int bsc = blocksize_code(bs);
+    bw_put(w, 0xFFF8, 16);
+    bw_put(w, (uint64_t)bsc, 4);
+    bw_put(w, 9, 4);  /* 44.1 kHz: libFLAC default sample rate, the reference never sets one */
+    bw_put(w, (uint64_t)(nch - 1), 4);  /* mono / two independent channels */
+    bw_put(w, 7, 3);  /* 32 bits per sample */
+    bw_put(w, 0, 1);
+    put_utf8(w, frame_no);
+    if (bsc == 6) bw_put(w, (uint64_t)(bs - 1), 8);
+    else if (bsc == 7) bw_put(w, (uint64_t)(bs - 1), 16);
+    bw_put(w, crc8(w->buf + frame_start, (size_t)(w->nbits >> 3) - frame_start), 8);
+
+    for (int c = 0; c < nch; ++c) encode_subframe(w, xin + c, nch, bs, P, win, info ? &info[c] : NULL);
+
+    bw_align(w);
+    bw_reserve(w, 16);
+    uint16_t c = crc16(w->buf + frame_start, (size_t)(w->nbits >> 3) - frame_start);
+    bw_put(w, c, 16);
+    if (info)
+        for (int k = 0; k < nch; ++k) info[k].nbytes = (int32_t)((w->nbits >> 3) - frame_start);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -638,7 +650,7 @@ static void encode_frame(bitw_t *w, const int32_t *xin, int bs, uint64_t frame_n
  * ---------------------------------------------------------------------------------------- */
 static int64_t stream_header_bytes(int64_t nframes) { return 4 + 4 + 34 + 4 + 18 * nframes; }
 
-static int encode_stream(const int32_t *x, int64_t n, uint32_t level, uint8_t **out, int64_t *out_bytes,
+static int encode_stream(const int32_t *x, int nch, int64_t n, uint32_t level, uint8_t **out, int64_t *out_bytes,
                          oracle_frame_info *infos) {
     enc_params_t P = level_params(level);
     int B = P.blocksize;
@@ -658,7 +670,7 @@ static int encode_stream(const int32_t *x, int64_t n, uint32_t level, uint8_t **
     for (int64_t f = 0; f < nf; ++f) {
         int bs = (f == nf - 1) ? tail_bs : B;
         foff[f] = (int64_t)(w.nbits >> 3) - hb;
-        encode_frame(&w, x + f * B, bs, (uint64_t)f, &P, (bs == B) ? win : win_tail, infos ? &infos[f] : NULL);
+        encode_frame(&w, x + f * B * nch, nch, bs, (uint64_t)f, &P, (bs == B) ? win : win_tail, infos ? &infos[f * nch] : NULL);
     }
     if (w.err) { free(w.buf); free(win); free(win_tail); free(foff); return ERROR_ALLOC; }
     /* header */
@@ -670,7 +682,7 @@ static int encode_stream(const int32_t *x, int64_t n, uint32_t level, uint8_t **
     memset(s + 4, 0, 6); /* min/max frame size unknown */
     uint64_t ts = ((uint64_t)n < (1ULL << 36)) ? (uint64_t)n : 0;
     /* 20 bits rate (44100) | 3 bits ch-1 | 5 bits bps-1 | 36 bits total samples */
-    uint64_t packed = ((uint64_t)44100 << 44) | ((uint64_t)0 << 41) | ((uint64_t)31 << 36) | ts;
+    uint64_t packed = ((uint64_t)44100 << 44) | ((uint64_t)(nch - 1) << 41) | ((uint64_t)31 << 36) | ts;
     for (int i = 0; i < 8; ++i) s[10 + i] = (uint8_t)(packed >> (56 - 8 * i));
     memset(s + 18, 0, 16); /* MD5 not computed */
     uint8_t *t = h + 42;
@@ -689,8 +701,8 @@ static int encode_stream(const int32_t *x, int64_t n, uint32_t level, uint8_t **
     return ERROR_NONE;
 }
 
-/* flacarray.h:209-227 encode_i32 / encode_i32_threaded; plumbing per compress.c:133-270 */
-int oracle_encode_i32(const int32_t *data, int64_t n_stream, int64_t stream_size, uint32_t level, int64_t *n_bytes,
+/* flacarray.h:209-247 encode_i32 / encode_i64 (+ _threaded); plumbing per compress.c:133-270 */
+static int encode_any(const int32_t *data, int nch, int64_t n_stream, int64_t stream_size, uint32_t level, int64_t *n_bytes,
                       int64_t *starts, unsigned char **bytes, int use_threads) {
     if (level > 8) return ERROR_INVALID_LEVEL;
     if (n_stream == 0) return ERROR_ZERO_NSTREAM;
@@ -705,7 +717,7 @@ int oracle_encode_i32(const int32_t *data, int64_t n_stream, int64_t stream_size
     int errors = ERROR_NONE;
 #pragma omp parallel for schedule(dynamic, 1) reduction(| : errors) if (use_threads)
     for (int64_t i = 0; i < n_stream; ++i)
-        errors |= encode_stream(data + i * stream_size, stream_size, level, &bufs[i], &sz[i], NULL);
+        errors |= encode_stream(data + i * stream_size * nch, nch, stream_size, level, &bufs[i], &sz[i], NULL);
     if (errors == ERROR_NONE) {
         int64_t total = 0;
         for (int64_t i = 0; i < n_stream; ++i) { starts[i] = total; total += sz[i]; }
@@ -723,12 +735,31 @@ int oracle_encode_i32(const int32_t *data, int64_t n_stream, int64_t stream_size
     return errors;
 }
 
-/* per-frame decisions of one stream, for parity debugging */
+int oracle_encode_i32(const int32_t *data, int64_t n_stream, int64_t stream_size, uint32_t level, int64_t *n_bytes,
+                      int64_t *starts, unsigned char **bytes, int use_threads) {
+    return encode_any(data, 1, n_stream, stream_size, level, n_bytes, starts, bytes, use_threads);
+}
+/* int64 samples are two interleaved int32 channels, low word first on this little-endian target
+ * (compress.c:482-511 with utils.c:110-123) */
+int oracle_encode_i64(const int64_t *data, int64_t n_stream, int64_t stream_size, uint32_t level, int64_t *n_bytes,
+                      int64_t *starts, unsigned char **bytes, int use_threads) {
+    return encode_any((const int32_t *)data, 2, n_stream, stream_size, level, n_bytes, starts, bytes, use_threads);
+}
+
+/* per-frame (per-subframe for nch == 2: infos[f * nch + c]) decisions of one stream, for parity debugging */
 int oracle_encode_stream_info(const int32_t *data, int64_t stream_size, uint32_t level, oracle_frame_info *infos) {
     crc_init();
     uint8_t *b = NULL;
     int64_t nb = 0;
-    int e = encode_stream(data, stream_size, level, &b, &nb, infos);
+    int e = encode_stream(data, 1, stream_size, level, &b, &nb, infos);
+    free(b);
+    return e;
+}
+int oracle_encode_stream_info_i64(const int64_t *data, int64_t stream_size, uint32_t level, oracle_frame_info *infos) {
+    crc_init();
+    uint8_t *b = NULL;
+    int64_t nb = 0;
+    int e = encode_stream((const int32_t *)data, 2, stream_size, level, &b, &nb, infos);
     free(b);
     return e;
 }
@@ -809,9 +840,65 @@ static int decode_residual(bitr_t *r, int32_t *res, int bs, int order) {
     return 0;
 }
 
-/* decode one frame at byte offset *off; returns blocksize or -1 */
-static int decode_frame(const uint8_t *s, int64_t nbytes, int64_t *off, int si_bps, int si_bs, int32_t *out) {
+/* one subframe of `bps` (up to 33: side channels) bits per sample into 64-bit samples */
+static int decode_subframe(bitr_t *r, int bs, int bps, int64_t *out) {
     static __thread int32_t res[65536];
+    if (br_get(r, 1)) return -1;
+    int tc = (int)br_get(r, 6);
+    int wasted = 0;
+    if (br_get(r, 1)) wasted = (int)br_unary(r) + 1;
+    bps -= wasted;
+    if (bps <= 0) return -1;
+    if (tc == 0) {
+        int64_t v = br_get_signed(r, (unsigned)bps);
+        for (int i = 0; i < bs; ++i) out[i] = v;
+    } else if (tc == 1) {
+        for (int i = 0; i < bs; ++i) out[i] = br_get_signed(r, (unsigned)bps);
+    } else if (tc >= 8 && tc <= 12) {
+        int order = tc - 8;
+        if (order > bs) return -1;
+        for (int i = 0; i < order; ++i) out[i] = br_get_signed(r, (unsigned)bps);
+        if (decode_residual(r, res, bs, order)) return -1;
+        for (int i = order; i < bs; ++i) {
+            int64_t p;
+            switch (order) {
+                case 0: p = 0; break;
+                case 1: p = out[i - 1]; break;
+                case 2: p = 2 * out[i - 1] - out[i - 2]; break;
+                case 3: p = 3 * out[i - 1] - 3 * out[i - 2] + out[i - 3]; break;
+                default: p = 4 * out[i - 1] - 6 * out[i - 2] + 4 * out[i - 3] - out[i - 4]; break;
+            }
+            out[i] = p + res[i];
+        }
+    } else if (tc >= 32) {
+        int order = (tc & 31) + 1;
+        if (order > bs) return -1;
+        for (int i = 0; i < order; ++i) out[i] = br_get_signed(r, (unsigned)bps);
+        int prec = (int)br_get(r, 4) + 1;
+        if (prec == 16) return -1;
+        int sh = (int)br_get_signed(r, 5);
+        if (sh < 0) return -1;
+        int32_t q[32];
+        for (int j = 0; j < order; ++j) q[j] = (int32_t)br_get_signed(r, (unsigned)prec);
+        if (decode_residual(r, res, bs, order)) return -1;
+        for (int i = order; i < bs; ++i) {
+            int64_t sum = 0;
+            for (int j = 0; j < order; ++j) sum += (int64_t)q[j] * out[i - 1 - j];
+            out[i] = (sum >> sh) + res[i];
+        }
+    } else {
+        return -1;
+    }
+    if (r->err) return -1;
+    if (wasted) for (int i = 0; i < bs; ++i) out[i] = (int64_t)((uint64_t)out[i] << wasted);
+    return 0;
+}
+
+/* decode one frame at byte offset *off into sample-interleaved int32 (nch channels); returns the
+ * blocksize or -1.  Channel assignments: 0 mono, 1 left/right, 8 left/side, 9 side/right,
+ * 10 mid/side (RFC 9639 9.1.3; the side channel carries one extra bit). */
+static int decode_frame(const uint8_t *s, int64_t nbytes, int64_t *off, int si_bps, int nch, int32_t *out) {
+    static __thread int64_t c0[65536], c1[65536];
     bitr_t r = {s, nbytes, (*off) * 8, 0};
     int64_t start = *off;
     if (br_get(&r, 14) != 0x3FFE) return -1;
@@ -822,7 +909,8 @@ static int decode_frame(const uint8_t *s, int64_t nbytes, int64_t *off, int si_b
     int ch = (int)br_get(&r, 4);
     int ssc = (int)br_get(&r, 3);
     if (br_get(&r, 1)) return -1;
-    if (ch != 0 || variable) return -1; /* mono fixed-blocksize streams only (n_channels=1 path) */
+    if (variable) return -1; /* fixed-blocksize streams only */
+    if (nch == 1 ? (ch != 0) : !(ch == 1 || (ch >= 8 && ch <= 10))) return -1;
     /* utf-8 number */
     int first = (int)br_get(&r, 8);
     int extra = 0;
@@ -845,56 +933,26 @@ static int decode_frame(const uint8_t *s, int64_t nbytes, int64_t *off, int si_b
     int bps = ssbits[ssc];
     if (bps == 0) bps = si_bps;
     if (bps < 0) return -1;
-    (void)si_bs;
-    /* subframe */
-    if (br_get(&r, 1)) return -1;
-    int tc = (int)br_get(&r, 6);
-    int wasted = 0;
-    if (br_get(&r, 1)) wasted = (int)br_unary(&r) + 1;
-    bps -= wasted;
-    if (bps <= 0) return -1;
-    if (tc == 0) {
-        int32_t v = (int32_t)br_get_signed(&r, (unsigned)bps);
-        for (int i = 0; i < bs; ++i) out[i] = v;
-    } else if (tc == 1) {
-        for (int i = 0; i < bs; ++i) out[i] = (int32_t)br_get_signed(&r, (unsigned)bps);
-    } else if (tc >= 8 && tc <= 12) {
-        int order = tc - 8;
-        if (order > bs) return -1;
-        for (int i = 0; i < order; ++i) out[i] = (int32_t)br_get_signed(&r, (unsigned)bps);
-        if (decode_residual(&r, res, bs, order)) return -1;
-        for (int i = order; i < bs; ++i) {
-            int64_t p;
-            switch (order) {
-                case 0: p = 0; break;
-                case 1: p = out[i - 1]; break;
-                case 2: p = 2 * (int64_t)out[i - 1] - out[i - 2]; break;
-                case 3: p = 3 * (int64_t)out[i - 1] - 3 * (int64_t)out[i - 2] + out[i - 3]; break;
-                default: p = 4 * (int64_t)out[i - 1] - 6 * (int64_t)out[i - 2] + 4 * (int64_t)out[i - 3] - out[i - 4]; break;
-            }
-            out[i] = (int32_t)(p + res[i]);
-        }
-    } else if (tc >= 32) {
-        int order = (tc & 31) + 1;
-        if (order > bs) return -1;
-        for (int i = 0; i < order; ++i) out[i] = (int32_t)br_get_signed(&r, (unsigned)bps);
-        int prec = (int)br_get(&r, 4) + 1;
-        if (prec == 16) return -1;
-        int sh = (int)br_get_signed(&r, 5);
-        if (sh < 0) return -1;
-        int32_t q[32];
-        for (int j = 0; j < order; ++j) q[j] = (int32_t)br_get_signed(&r, (unsigned)prec);
-        if (decode_residual(&r, res, bs, order)) return -1;
-        for (int i = order; i < bs; ++i) {
-            int64_t sum = 0;
-            for (int j = 0; j < order; ++j) sum += (int64_t)q[j] * (int64_t)out[i - 1 - j];
-            out[i] = (int32_t)((sum >> sh) + res[i]);
-        }
+    if (nch == 1) {
+        if (decode_subframe(&r, bs, bps, c0)) return -1;
+        for (int i = 0; i < bs; ++i) out[i] = (int32_t)c0[i];
     } else {
-        return -1;
+        if (decode_subframe(&r, bs, bps + (ch == 9 ? 1 : 0), c0)) return -1;
+        if (decode_subframe(&r, bs, bps + ((ch == 8 || ch == 10) ? 1 : 0), c1)) return -1;
+        for (int i = 0; i < bs; ++i) {
+            int64_t L, R;
+            if (ch == 1) { L = c0[i]; R = c1[i]; }
+            else if (ch == 8) { L = c0[i]; R = c0[i] - c1[i]; }
+            else if (ch == 9) { R = c1[i]; L = c0[i] + c1[i]; }
+            else {
+                int64_t mid = (int64_t)((uint64_t)c0[i] << 1) | (c1[i] & 1), side = c1[i];
+                L = (mid + side) >> 1;
+                R = (mid - side) >> 1;
+            }
+            out[2 * i] = (int32_t)L;
+            out[2 * i + 1] = (int32_t)R;
+        }
     }
-    if (r.err) return -1;
-    if (wasted) for (int i = 0; i < bs; ++i) out[i] = (int32_t)((uint32_t)out[i] << wasted);
     r.pos = (r.pos + 7) & ~(int64_t)7;
     uint16_t c16 = (uint16_t)br_get(&r, 16);
     if (r.err) return -1;
@@ -903,10 +961,10 @@ static int decode_frame(const uint8_t *s, int64_t nbytes, int64_t *off, int si_b
     return bs;
 }
 
-static int decode_stream(const uint8_t *s, int64_t nbytes, int64_t stream_size, int64_t first, int64_t n_decode, int32_t *out) {
+static int decode_stream(const uint8_t *s, int64_t nbytes, int nch, int64_t stream_size, int64_t first, int64_t n_decode, int32_t *out) {
     if (nbytes < 42 || memcmp(s, "fLaC", 4) != 0) return ERROR_DECODE_INIT;
     int64_t off = 4;
-    int si_bps = 0, si_bs = 0;
+    int si_bps = 0, si_ch = 0;
     while (1) {
         if (off + 4 > nbytes) return ERROR_DECODE_INIT;
         int last = s[off] >> 7, type = s[off] & 0x7f;
@@ -914,21 +972,23 @@ static int decode_stream(const uint8_t *s, int64_t nbytes, int64_t stream_size, 
         off += 4;
         if (off + len > nbytes) return ERROR_DECODE_INIT;
         if (type == 0 && len >= 34) {
-            si_bs = (s[off + 2] << 8) | s[off + 3];
+            si_ch = ((s[off + 12] >> 1) & 7) + 1;
             si_bps = (((s[off + 12] & 1) << 4) | (s[off + 13] >> 4)) + 1;
         }
         off += len;
         if (last) break;
     }
-    static __thread int32_t frame[65536];
+    if (si_ch != nch) return ERROR_DECODE_INIT;
+    static __thread int32_t frame[2 * 65536];
     int64_t done = 0; /* samples seen */
     while (done < first + n_decode) {
         if (off >= nbytes) return ERROR_DECODE_PROCESS;
-        int bs = decode_frame(s, nbytes, &off, si_bps, si_bs, frame);
+        int bs = decode_frame(s, nbytes, &off, si_bps, nch, frame);
         if (bs < 0) return ERROR_DECODE_PROCESS;
         for (int i = 0; i < bs; ++i) {
             int64_t g = done + i;
-            if (g >= first && g < first + n_decode) out[g - first] = frame[i];
+            if (g >= first && g < first + n_decode)
+                for (int c = 0; c < nch; ++c) out[(g - first) * nch + c] = frame[i * nch + c];
         }
         done += bs;
     }
@@ -936,8 +996,8 @@ static int decode_stream(const uint8_t *s, int64_t nbytes, int64_t stream_size, 
     return ERROR_NONE;
 }
 
-/* flacarray.h:249-259 decode_i32; semantics per decompress.c:194-313 */
-int oracle_decode_i32(const unsigned char *bytes, const int64_t *starts, const int64_t *nbytes, int64_t n_stream,
+/* flacarray.h:249-271 decode_i32 / decode_i64; semantics per decompress.c:194-313 */
+static int decode_any(const unsigned char *bytes, const int64_t *starts, const int64_t *nbytes, int nch, int64_t n_stream,
                       int64_t stream_size, int64_t first_sample, int64_t last_sample, int32_t *data, int use_threads) {
     crc_init();
     int64_t first_decode = 0, n_decode = stream_size;
@@ -951,8 +1011,16 @@ int oracle_decode_i32(const unsigned char *bytes, const int64_t *starts, const i
     int errors = ERROR_NONE;
 #pragma omp parallel for schedule(dynamic, 1) reduction(| : errors) if (use_threads)
     for (int64_t i = 0; i < n_stream; ++i)
-        errors |= decode_stream(bytes + starts[i], nbytes[i], stream_size, first_decode, n_decode, data + i * n_decode);
+        errors |= decode_stream(bytes + starts[i], nbytes[i], nch, stream_size, first_decode, n_decode, data + i * n_decode * nch);
     return errors;
+}
+int oracle_decode_i32(const unsigned char *bytes, const int64_t *starts, const int64_t *nbytes, int64_t n_stream,
+                      int64_t stream_size, int64_t first_sample, int64_t last_sample, int32_t *data, int use_threads) {
+    return decode_any(bytes, starts, nbytes, 1, n_stream, stream_size, first_sample, last_sample, data, use_threads);
+}
+int oracle_decode_i64(const unsigned char *bytes, const int64_t *starts, const int64_t *nbytes, int64_t n_stream,
+                      int64_t stream_size, int64_t first_sample, int64_t last_sample, int64_t *data, int use_threads) {
+    return decode_any(bytes, starts, nbytes, 2, n_stream, stream_size, first_sample, last_sample, (int32_t *)data, use_threads);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1011,6 +1079,44 @@ void oracle_int32_to_float32(const int32_t *input, int64_t n_stream, int64_t str
             float prod = coeff * (float)input[is * stream_size + i];
             output[is * stream_size + i] = offsets[is] + prod;            /* utils.c:364 */
         }
+    }
+}
+
+/* utils.c:245-327 float64_to_int64: all arithmetic in double; the (int64_t) casts truncate toward
+ * zero and give INT64_MIN out of range on x86-64 (cvttsd2si), reproduced by to_i64() */
+int oracle_float64_to_int64(const double *input, int64_t n_stream, int64_t stream_size, const double *quanta,
+                            int64_t *output, double *offsets, double *gains) {
+    const int64_t flac_max = 9223372036854775807LL;
+    for (int64_t s = 0; s < n_stream; ++s) {
+        const double *x = input + s * stream_size;
+        double smin = x[0], smax = x[0];
+        for (int64_t i = 1; i < stream_size; ++i) {
+            if (x[i] < smin) smin = x[i];
+            if (x[i] > smax) smax = x[i];
+        }
+        double off = 0.5 * (smin + smax);
+        double amp = ((smin - off) > (smax - off)) ? 1.01 * (smin - off) : 1.01 * (smax - off);
+        double min_quanta = amp / (double)flac_max;
+        double squanta = quanta ? quanta[s] : min_quanta;
+        int64_t nquant = to_i64(off / squanta);
+        off = squanta * (double)nquant;
+        double gain = (squanta == 0) ? 1.0 : 1.0 / squanta;
+        offsets[s] = off;
+        gains[s] = gain;
+        for (int64_t i = 0; i < stream_size; ++i) {
+            double t = x[i] - off;
+            output[s * stream_size + i] = (t >= 0) ? to_i64(gain * t + 0.5) : to_i64(gain * t - 0.5);
+        }
+    }
+    return ERROR_NONE;
+}
+
+/* utils.c:329-348 int64_to_float64 */
+void oracle_int64_to_float64(const int64_t *input, int64_t n_stream, int64_t stream_size, const double *offsets,
+                             const double *gains, double *output) {
+    for (int64_t s = 0; s < n_stream; ++s) {
+        double coeff = 1.0 / gains[s];
+        for (int64_t i = 0; i < stream_size; ++i) output[s * stream_size + i] = offsets[s] + coeff * (double)input[s * stream_size + i];
     }
 }
 

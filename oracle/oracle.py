@@ -51,6 +51,17 @@ def lib():
         L.oracle_int32_to_float32.restype = None
         L.oracle_encode_stream_info.argtypes = [i32p, i64, ctypes.c_uint32, ctypes.POINTER(FrameInfo)]
         L.oracle_encode_stream_info.restype = ctypes.c_int
+        f64p = ctypes.POINTER(ctypes.c_double)
+        L.oracle_encode_i64.argtypes = [i64p, i64, i64, ctypes.c_uint32, i64p, i64p, ctypes.POINTER(u8p), ctypes.c_int]
+        L.oracle_encode_i64.restype = ctypes.c_int
+        L.oracle_decode_i64.argtypes = [u8p, i64p, i64p, i64, i64, i64, i64, i64p, ctypes.c_int]
+        L.oracle_decode_i64.restype = ctypes.c_int
+        L.oracle_float64_to_int64.argtypes = [f64p, i64, i64, f64p, i64p, f64p, f64p]
+        L.oracle_float64_to_int64.restype = ctypes.c_int
+        L.oracle_int64_to_float64.argtypes = [i64p, i64, i64, f64p, f64p, f64p]
+        L.oracle_int64_to_float64.restype = None
+        L.oracle_encode_stream_info_i64.argtypes = [i64p, i64, ctypes.c_uint32, ctypes.POINTER(FrameInfo)]
+        L.oracle_encode_stream_info_i64.restype = ctypes.c_int
         L.oracle_free.argtypes = [ctypes.c_void_p]
         L.oracle_tukey_window.argtypes = [ctypes.c_int, f32p]
         L.oracle_det_log2.argtypes = [ctypes.c_double]
@@ -66,17 +77,18 @@ def _p(a, t):
     return a.ctypes.data_as(ctypes.POINTER(t))
 
 
-def encode_i32(data, level=5, use_threads=False):
+def encode_i32(data, level=5, use_threads=False, _dtype=np.int32):
     """(blob uint8, starts int64[n_stream], nbytes int64[n_stream]) for a 2-D C-contiguous int32 array."""
-    data = np.ascontiguousarray(data, dtype=np.int32)
+    data = np.ascontiguousarray(data, dtype=_dtype)
     if data.ndim == 1:
         data = data.reshape(1, -1)
     n_stream, stream_size = data.shape
     starts = np.zeros(n_stream, dtype=np.int64)
     n_bytes = ctypes.c_int64(0)
     raw = ctypes.POINTER(ctypes.c_uint8)()
-    err = lib().oracle_encode_i32(
-        _p(data, ctypes.c_int32), n_stream, stream_size, level, ctypes.byref(n_bytes), _p(starts, ctypes.c_int64),
+    fn, ct = (lib().oracle_encode_i32, ctypes.c_int32) if _dtype == np.int32 else (lib().oracle_encode_i64, ctypes.c_int64)
+    err = fn(
+        _p(data, ct), n_stream, stream_size, level, ctypes.byref(n_bytes), _p(starts, ctypes.c_int64),
         ctypes.byref(raw), int(use_threads),
     )
     if err != 0:
@@ -89,16 +101,26 @@ def encode_i32(data, level=5, use_threads=False):
     return blob, starts, nbytes
 
 
-def decode_i32(blob, starts, nbytes, stream_size, first=-1, last=-1, use_threads=False):
+def encode_i64(data, level=5, use_threads=False):
+    """Two-channel streams for a 2-D int64 array (channel 0 = low words, channel 1 = high words)."""
+    return encode_i32(data, level, use_threads, _dtype=np.int64)
+
+
+def decode_i64(blob, starts, nbytes, stream_size, first=-1, last=-1, use_threads=False):
+    return decode_i32(blob, starts, nbytes, stream_size, first, last, use_threads, _dtype=np.int64)
+
+
+def decode_i32(blob, starts, nbytes, stream_size, first=-1, last=-1, use_threads=False, _dtype=np.int32):
     blob = np.ascontiguousarray(blob, dtype=np.uint8)
     starts = np.ascontiguousarray(starts, dtype=np.int64).reshape(-1)
     nbytes = np.ascontiguousarray(nbytes, dtype=np.int64).reshape(-1)
     n_stream = starts.shape[0]
     n_decode = stream_size if (first < 0 or last < 0) else last - first
-    out = np.empty((n_stream, max(n_decode, 0)), dtype=np.int32)
-    err = lib().oracle_decode_i32(
+    out = np.empty((n_stream, max(n_decode, 0)), dtype=_dtype)
+    fn, ct = (lib().oracle_decode_i32, ctypes.c_int32) if _dtype == np.int32 else (lib().oracle_decode_i64, ctypes.c_int64)
+    err = fn(
         _p(blob, ctypes.c_uint8), _p(starts, ctypes.c_int64), _p(nbytes, ctypes.c_int64), n_stream, stream_size,
-        first, last, _p(out, ctypes.c_int32), int(use_threads),
+        first, last, _p(out, ct), int(use_threads),
     )
     if err != 0:
         raise RuntimeError(f"Decoding failed, return code = {err}")
@@ -138,6 +160,53 @@ def int32_to_float32(idata, offsets, gains):
         _p(out, ctypes.c_float),
     )
     return out
+
+
+def float64_to_int64(data, quanta=None):
+    data = np.ascontiguousarray(data, dtype=np.float64)
+    if data.ndim == 1:
+        data = data.reshape(1, -1)
+    n_stream, stream_size = data.shape
+    out = np.empty(data.shape, dtype=np.int64)
+    offsets = np.empty(n_stream, dtype=np.float64)
+    gains = np.empty(n_stream, dtype=np.float64)
+    qp = None
+    if quanta is not None:
+        quanta = np.ascontiguousarray(quanta, dtype=np.float64).reshape(-1)
+        assert quanta.shape[0] == n_stream
+        qp = _p(quanta, ctypes.c_double)
+    lib().oracle_float64_to_int64(
+        _p(data, ctypes.c_double), n_stream, stream_size, qp, _p(out, ctypes.c_int64), _p(offsets, ctypes.c_double),
+        _p(gains, ctypes.c_double),
+    )
+    return out, offsets, gains
+
+
+def int64_to_float64(idata, offsets, gains):
+    idata = np.ascontiguousarray(idata, dtype=np.int64)
+    if idata.ndim == 1:
+        idata = idata.reshape(1, -1)
+    n_stream, stream_size = idata.shape
+    offsets = np.ascontiguousarray(offsets, dtype=np.float64).reshape(-1)
+    gains = np.ascontiguousarray(gains, dtype=np.float64).reshape(-1)
+    out = np.empty(idata.shape, dtype=np.float64)
+    lib().oracle_int64_to_float64(
+        _p(idata, ctypes.c_int64), n_stream, stream_size, _p(offsets, ctypes.c_double), _p(gains, ctypes.c_double),
+        _p(out, ctypes.c_double),
+    )
+    return out
+
+
+def stream_info_i64(x, level=5):
+    """Per-SUBFRAME encoder decisions for one 1-D int64 stream: entry [2 * frame + channel]."""
+    x = np.ascontiguousarray(x, dtype=np.int64).reshape(-1)
+    bs = 1152 if level <= 2 else 4096
+    nf = (x.shape[0] + bs - 1) // bs
+    infos = (FrameInfo * (2 * nf))()
+    err = lib().oracle_encode_stream_info_i64(_p(x, ctypes.c_int64), x.shape[0], level, infos)
+    if err != 0:
+        raise RuntimeError(f"Encoding failed, return code = {err}")
+    return [{k: getattr(i, k) for k, _ in FrameInfo._fields_} for i in infos]
 
 
 def stream_info(x, level=5):

@@ -94,20 +94,12 @@ def residual(res, order, porder, params, bs, rice2=False, escapes=None):
     return out
 
 
-def frame(samples, frame_no, bps, sub, ss_code=None, force_bs_code=None):
+def subframe_bits(samples, bps, sub):
     """sub: dict(type='const'|'verbatim'|'fixed'|'lpc', order, coefs, shift, precision, porder, params, rice2, wasted)."""
     bs = len(samples)
     wasted = sub.get("wasted", 0)
     x = [int(v) >> wasted for v in samples]
     b = bps - wasted
-    code = force_bs_code if force_bs_code is not None else BS_CODES.get(bs, 6 if bs <= 256 else 7)
-    hdr = "11111111111110" + "0" + "0" + ubits(code, 4) + ubits(9, 4) + ubits(0, 4) + ubits(SS_CODES[bps] if ss_code is None else ss_code, 3) + "0"
-    hdr += utf8(frame_no)
-    if code == 6:
-        hdr += ubits(bs - 1, 8)
-    elif code == 7:
-        hdr += ubits(bs - 1, 16)
-    hdr += ubits(crc8(to_bytes(hdr)), 8)
     t = sub["type"]
     order = sub.get("order", 0)
     tc = {"const": 0, "verbatim": 1}.get(t)
@@ -133,14 +125,34 @@ def frame(samples, frame_no, bps, sub, ss_code=None, force_bs_code=None):
             pred = sum(c * x[i - 1 - j] for j, c in enumerate(coefs)) >> shift
             res.append(x[i] - pred)
         body += residual(res, order, sub["porder"], sub["params"], bs, sub.get("rice2", False))
-    bits = hdr + body
+    return body
+
+
+def frame(samples, frame_no, bps, sub, ss_code=None, force_bs_code=None, assignment=0):
+    """One frame.  Mono: `samples` is the channel and `sub` its description.  Two channels
+    (assignment 1 left/right, 8 left/side, 9 side/right, 10 mid/side): `samples` is the pair of
+    CODED channels (the caller has already formed side / mid) and `sub` the pair of descriptions;
+    a side channel is coded with one extra bit per sample."""
+    chans = [samples] if assignment == 0 else list(samples)
+    subs = [sub] if assignment == 0 else list(sub)
+    bs = len(chans[0])
+    code = force_bs_code if force_bs_code is not None else BS_CODES.get(bs, 6 if bs <= 256 else 7)
+    hdr = "11111111111110" + "0" + "0" + ubits(code, 4) + ubits(9, 4) + ubits(assignment, 4) + ubits(SS_CODES[bps] if ss_code is None else ss_code, 3) + "0"
+    hdr += utf8(frame_no)
+    if code == 6:
+        hdr += ubits(bs - 1, 8)
+    elif code == 7:
+        hdr += ubits(bs - 1, 16)
+    hdr += ubits(crc8(to_bytes(hdr)), 8)
+    extra = {0: [0], 1: [0, 0], 8: [0, 1], 9: [1, 0], 10: [0, 1]}[assignment]
+    bits = hdr + "".join(subframe_bits(c, bps + e, sb) for c, e, sb in zip(chans, extra, subs))
     bits += "0" * ((-len(bits)) % 8)
     raw = to_bytes(bits)
     return raw + crc16(raw).to_bytes(2, "big")
 
 
-def stream(frames_bytes, blocksize, bps, total, extra_blocks=()):
-    si = ubits(blocksize, 16) * 2 + ubits(0, 24) * 2 + ubits(44100, 20) + ubits(0, 3) + ubits(bps - 1, 5) + ubits(total, 36) + "0" * 128
+def stream(frames_bytes, blocksize, bps, total, extra_blocks=(), channels=1):
+    si = ubits(blocksize, 16) * 2 + ubits(0, 24) * 2 + ubits(44100, 20) + ubits(channels - 1, 3) + ubits(bps - 1, 5) + ubits(total, 36) + "0" * 128
     blocks = [(0, to_bytes(si))] + list(extra_blocks)
     out = b"fLaC"
     for i, (typ, payload) in enumerate(blocks):
@@ -198,6 +210,52 @@ def build():
                "porder": 0, "params": [20], "rice2": True}
         frs.append(frame(blk, f, 24, sub))
     add("g7_deep", s, stream(frs, 64, 24, len(s)), len(s))
+    # ---- two-channel streams: int64 samples = (channel 1 << 32) | (channel 0 as unsigned), the
+    #      reference's split of int64 data into low / high words (utils.c:96-123) ----
+    def add64(name, left, right, data):
+        s64 = [(int(r) << 32) | (int(l) & 0xFFFFFFFF) for l, r in zip(left, right)]
+        vec[name + "_samples"] = np.asarray(s64, dtype=np.int64)
+        vec[name + "_stream"] = np.frombuffer(data, dtype=np.uint8)
+        vec[name + "_size"] = np.int64(len(s64))
+
+    n2 = 192
+    ext = [2**31 - 1, -(2**31), -(2**31), 2**31 - 1, 0, -1, 1, 2**31 - 1]  # pairs that need all 33 bits of a side channel
+    left = ext + rng.integers(-(2**31), 2**31, n2 - len(ext)).tolist()
+    right = ext[::-1] + (np.cumsum(rng.integers(-9, 10, n2 - len(ext))) - 40).tolist()
+    vb = {"type": "verbatim"}
+    r0 = {"type": "fixed", "order": 0, "porder": 2, "params": [30, 7, 7, 7], "rice2": True}  # extremes only in the first partition
+    # g8: independent channels: low word VERBATIM, high word FIXED order 0 (the encoder's own layout)
+    add64("g8_stereo_lr", left, right, stream([frame([left, right], 0, 32, [vb, r0], assignment=1)], n2, 32, n2, channels=2))
+    side = [l - r for l, r in zip(left, right)]
+    mid = [(l + r) >> 1 for l, r in zip(left, right)]
+    # g9: left/side, g10: side/right (33-bit VERBATIM side: its extremes +-(2^32 - 1) fit no 32-bit residual),
+    # g11: mid/side with a Rice2-coded mid
+    add64("g9_stereo_ls", left, right, stream([frame([left, side], 0, 32, [vb, vb], assignment=8)], n2, 32, n2, channels=2))
+    add64("g10_stereo_sr", left, right, stream([frame([side, right], 0, 32, [vb, r0], assignment=9)], n2, 32, n2, channels=2))
+    add64("g11_stereo_ms", left, right, stream([frame([mid, side], 0, 32, [{"type": "fixed", "order": 0, "porder": 0, "params": [30], "rice2": True}, vb],
+                                                      assignment=10)], n2, 32, n2, channels=2))
+    # g13: predictive 33-bit side channels: left near +2^31, right near -2^31, both smooth, so the side
+    #      (about 2^32) needs 33-bit warm-up samples and a 64-bit predictor, while its residual is tiny
+    t2 = np.arange(n2)
+    lft = (2**31 - 5000 + np.rint(900 * np.sin(t2 / 7.0))).astype(np.int64) + rng.integers(-3, 4, n2)
+    rgt = (-(2**31) + 5000 + np.rint(700 * np.cos(t2 / 5.0))).astype(np.int64) + rng.integers(-3, 4, n2)
+    lft, rgt = lft.tolist(), rgt.tolist()
+    sd = [a - c for a, c in zip(lft, rgt)]
+    md = [(a + c) >> 1 for a, c in zip(lft, rgt)]
+    lp = {"type": "lpc", "order": 2, "coefs": [1024, -512], "shift": 9, "precision": 12, "porder": 1, "params": [8, 8]}
+    fx = {"type": "fixed", "order": 2, "porder": 0, "params": [7]}
+    frs = [frame([lft[:64], sd[:64]], 0, 32, [fx, lp], assignment=8),
+           frame([sd[64:128], rgt[64:128]], 1, 32, [fx, fx], assignment=9),
+           frame([md[128:], sd[128:]], 2, 32, [lp, fx], assignment=10)]
+    add64("g13_stereo_pred", lft, rgt, stream(frs, 64, 32, n2, channels=2))
+    # g12: two frames of 16-bit stereo (sample size from the frame header), mid/side then left/right, wasted bits on one channel
+    l16 = (rng.integers(-2000, 2000, 32) * 4).tolist()
+    r16 = rng.integers(-30000, 30000, 32).tolist()
+    m16 = [(a + c) >> 1 for a, c in zip(l16[:16], r16[:16])]
+    s16 = [a - c for a, c in zip(l16[:16], r16[:16])]
+    f0 = frame([m16, s16], 0, 16, [{"type": "verbatim"}, {"type": "fixed", "order": 0, "porder": 0, "params": [14]}], assignment=10)
+    f1 = frame([l16[16:], r16[16:]], 1, 16, [{"type": "fixed", "order": 0, "porder": 0, "params": [9], "wasted": 2}, {"type": "verbatim"}], assignment=1)
+    add64("g12_stereo16", l16, r16, stream([f0, f1], 16, 16, 32, channels=2))
     vec["crc8_check"] = np.uint8(crc8(b"123456789"))
     vec["crc16_check"] = np.uint16(crc16(b"123456789"))
     return vec

@@ -1,7 +1,8 @@
 """Independent pure-Python native-FLAC decoder (RFC 9639), used only by the tests to pin the
 oracle ENCODER: it shares no code with oracle/ or flacarray_amd/ and works on a Python bit
-string, one field at a time.  Mono streams, every subframe type, Rice/Rice2, escapes, wasted
-bits; both CRCs are verified."""
+string, one field at a time.  Mono and two-channel streams (left/right, left/side, side/right,
+mid/side; sample-interleaved output), every subframe type, Rice/Rice2, escapes, wasted bits;
+both CRCs are verified."""
 from .make_golden import crc8, crc16
 
 
@@ -67,7 +68,7 @@ def decode_stream(data):
         assert b.u(14) == 0x3FFE and b.u(1) == 0
         assert b.u(1) == 0, "fixed blocksize expected"
         bsc, src, ch, ssc = b.u(4), b.u(4), b.u(4), b.u(3)
-        assert b.u(1) == 0 and ch == 0
+        assert b.u(1) == 0
         first = b.u(8)
         num = first
         if first & 0x80:
@@ -93,63 +94,89 @@ def decode_stream(data):
         assert src == 9
         hdr_end = b.pos // 8
         assert b.u(8) == crc8(data[start:hdr_end]), "CRC-8"
-        bps = {0: info["bps"], 1: 8, 2: 12, 4: 16, 5: 20, 6: 24, 7: 32}[ssc]
-        assert b.u(1) == 0
-        tc = b.u(6)
-        wasted = b.unary() + 1 if b.u(1) else 0
-        bps -= wasted
-        desc = {"bs": bs, "wasted": wasted, "offset": start}
-        if tc == 0:
-            x = [b.s(bps)] * bs
-            desc["type"] = "const"
-        elif tc == 1:
-            x = [b.s(bps) for _ in range(bs)]
-            desc["type"] = "verbatim"
-        else:
-            if 8 <= tc <= 12:
-                order = tc - 8
-                desc["type"] = "fixed"
-                x = [b.s(bps) for _ in range(order)]
-                coefs, shift = {0: [], 1: [1], 2: [2, -1], 3: [3, -3, 1], 4: [4, -6, 4, -1]}[order], 0
+        bps0 = {0: info["bps"], 1: 8, 2: 12, 4: 16, 5: 20, 6: 24, 7: 32}[ssc]
+
+        def subframe(bps):
+            assert b.u(1) == 0
+            tc = b.u(6)
+            wasted = b.unary() + 1 if b.u(1) else 0
+            bps -= wasted
+            desc = {"bs": bs, "wasted": wasted, "offset": start}
+            if tc == 0:
+                x = [b.s(bps)] * bs
+                desc["type"] = "const"
+            elif tc == 1:
+                x = [b.s(bps) for _ in range(bs)]
+                desc["type"] = "verbatim"
             else:
-                assert tc >= 32
-                order = (tc & 31) + 1
-                desc["type"] = "lpc"
-                x = [b.s(bps) for _ in range(order)]
-                prec = b.u(4) + 1
-                assert prec != 16
-                shift = b.s(5)
-                assert shift >= 0
-                coefs = [b.s(prec) for _ in range(order)]
-                desc["precision"], desc["shift"] = prec, shift
-            desc["order"] = order
-            method = b.u(2)
-            assert method < 2
-            po = b.u(4)
-            plen, esc = (5, 31) if method else (4, 15)
-            desc["porder"], desc["rice2"], desc["params"] = po, bool(method), []
-            res = []
-            for p in range(1 << po):
-                n = (bs >> po) - (order if p == 0 else 0)
-                k = b.u(plen)
-                if k == esc:
-                    w = b.u(5)
-                    desc["params"].append(("esc", w))
-                    res += [b.s(w) for _ in range(n)]
+                if 8 <= tc <= 12:
+                    order = tc - 8
+                    desc["type"] = "fixed"
+                    x = [b.s(bps) for _ in range(order)]
+                    coefs, shift = {0: [], 1: [1], 2: [2, -1], 3: [3, -3, 1], 4: [4, -6, 4, -1]}[order], 0
                 else:
-                    desc["params"].append(k)
-                    for _ in range(n):
-                        q = b.unary()
-                        u = (q << k) | b.u(k)
-                        res.append((u >> 1) ^ -(u & 1))
-            for i in range(order, bs):
-                pred = sum(c * x[i - 1 - j] for j, c in enumerate(coefs)) >> shift
-                x.append(res[i - order] + pred)
+                    assert tc >= 32
+                    order = (tc & 31) + 1
+                    desc["type"] = "lpc"
+                    x = [b.s(bps) for _ in range(order)]
+                    prec = b.u(4) + 1
+                    assert prec != 16
+                    shift = b.s(5)
+                    assert shift >= 0
+                    coefs = [b.s(prec) for _ in range(order)]
+                    desc["precision"], desc["shift"] = prec, shift
+                desc["order"] = order
+                method = b.u(2)
+                assert method < 2
+                po = b.u(4)
+                plen, esc = (5, 31) if method else (4, 15)
+                desc["porder"], desc["rice2"], desc["params"] = po, bool(method), []
+                res = []
+                for p in range(1 << po):
+                    n = (bs >> po) - (order if p == 0 else 0)
+                    k = b.u(plen)
+                    if k == esc:
+                        w = b.u(5)
+                        desc["params"].append(("esc", w))
+                        res += [b.s(w) for _ in range(n)]
+                    else:
+                        desc["params"].append(k)
+                        for _ in range(n):
+                            q = b.unary()
+                            u = (q << k) | b.u(k)
+                            res.append((u >> 1) ^ -(u & 1))
+                for i in range(order, bs):
+                    pred = sum(c * x[i - 1 - j] for j, c in enumerate(coefs)) >> shift
+                    x.append(res[i - order] + pred)
+            return [v << wasted for v in x], desc
+
+        if info["channels"] == 1:
+            assert ch == 0
+            x, desc = subframe(bps0)
+        else:
+            # two channels, sample-interleaved output: left/right, left/side, side/right, mid/side
+            assert info["channels"] == 2 and ch in (1, 8, 9, 10)
+            c0, d0 = subframe(bps0 + (1 if ch == 9 else 0))
+            c1, d1 = subframe(bps0 + (1 if ch in (8, 10) else 0))
+            x = []
+            for u0, u1 in zip(c0, c1):
+                if ch == 1:
+                    left, right = u0, u1
+                elif ch == 8:
+                    left, right = u0, u0 - u1
+                elif ch == 9:
+                    left, right = u0 + u1, u1
+                else:
+                    mid = (u0 << 1) | (u1 & 1)
+                    left, right = (mid + u1) >> 1, (mid - u1) >> 1
+                assert -(1 << (bps0 - 1)) <= left < (1 << (bps0 - 1)) and -(1 << (bps0 - 1)) <= right < (1 << (bps0 - 1))
+                x += [left, right]
+            desc = {"bs": bs, "offset": start, "assignment": ch, "subs": [d0, d1]}
         b.pos = (b.pos + 7) & ~7
         end = b.pos // 8
         assert b.u(16) == crc16(data[start:end]), "CRC-16"
         off = end + 2
-        out += [v << wasted for v in x]
+        out += x
         frames.append(desc)
         fno += 1
     info["frames"] = frames

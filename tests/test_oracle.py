@@ -40,6 +40,80 @@ def test_oracle_decodes_hand_assembled_streams(oracle, name):
     assert np.array_equal(out[0], s) and np.array_equal(out[1], s)
 
 
+STEREO = ["g8_stereo_lr", "g9_stereo_ls", "g10_stereo_sr", "g11_stereo_ms", "g12_stereo16", "g13_stereo_pred"]
+
+
+def _split64(x):
+    """int64 -> sample-interleaved (low word as signed int32, high word) Python ints"""
+    x = np.asarray(x, dtype=np.int64).reshape(-1)
+    lo = (x & 0xFFFFFFFF).astype(np.uint32).view(np.int32).astype(np.int64)
+    return np.stack([lo, x >> 32], axis=1).reshape(-1).tolist()
+
+
+@pytest.mark.parametrize("name", STEREO)
+def test_oracle_decodes_hand_assembled_stereo_streams(oracle, name):
+    """Two-channel streams with every channel assignment libFLAC may choose for the reference's
+    int64 path (compress.c:482-511): left/right, left/side, side/right, mid/side, 33-bit sides."""
+    v = np.load(GOLDEN)
+    s, st, n = v[name + "_samples"], v[name + "_stream"], int(v[name + "_size"])
+    starts, nbytes = np.array([0], dtype=np.int64), np.array([st.size], dtype=np.int64)
+    assert np.array_equal(oracle.decode_i64(st, starts, nbytes, n)[0], s)
+    for first, last in ((0, 1), (n // 2, n), (max(n - 3, 0), n)):
+        assert np.array_equal(oracle.decode_i64(st, starts, nbytes, n, first, last)[0], s[first:last])
+    with pytest.raises(RuntimeError):  # a two-channel stream is not an int32 stream
+        oracle.decode_i32(st, starts, nbytes, n)
+
+
+@pytest.mark.parametrize("level", [0, 3, 5, 8])
+def test_oracle_i64_encoder_read_by_independent_decoder(oracle, level):
+    rng = np.random.default_rng(level)
+    n = 9000
+    cases = [
+        (np.cumsum(rng.integers(-(2**20), 2**20, n)) + 2**40).astype(np.int64),  # a counter above 2^32: low word wraps
+        rng.integers(-(2**62), 2**62, n).astype(np.int64),
+        np.full(n, -(2**63), dtype=np.int64),
+        (np.arange(n, dtype=np.int64) - 4500) * 1000003,
+    ]
+    cases[1][:4] = [2**63 - 1, -(2**63), 2**32, -1]
+    for x in cases:
+        blob, st, nb = oracle.encode_i64(x, level)
+        y, info = pyflac.decode_stream(blob.tobytes())
+        assert y == _split64(x)
+        assert info["channels"] == 2 and info["bps"] == 32 and info["total"] == n
+        assert all(f["assignment"] == 1 for f in info["frames"])
+        assert np.array_equal(oracle.decode_i64(blob, st, nb, n)[0], x)
+        assert np.array_equal(oracle.decode_i64(blob, st, nb, n, 4000, 4200)[0], x[4000:4200])
+
+
+def test_oracle_i64_channels_are_coded_like_mono_streams(oracle):
+    """Each channel of a two-channel stream gets exactly the subframe its samples would get alone."""
+    rng = np.random.default_rng(12)
+    x = (np.cumsum(rng.integers(-5000, 5000, 3 * 4096 + 100)) * 2**20).astype(np.int64)
+    lo = (x & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+    hi = (x >> 32).astype(np.int32)
+    i64, ilo, ihi = oracle.stream_info_i64(x, 5), oracle.stream_info(lo, 5), oracle.stream_info(hi, 5)
+    keys = ["type", "order", "porder", "wasted", "shift", "precision", "blocksize"]
+    for f in range(len(ilo)):
+        assert [i64[2 * f][k] for k in keys] == [ilo[f][k] for k in keys]
+        assert [i64[2 * f + 1][k] for k in keys] == [ihi[f][k] for k in keys]
+
+
+def test_float64_quantisation(oracle):
+    """utils.c:245-348 (tests/array.py:234-283 recipe in double precision)."""
+    rng = np.random.default_rng(5)
+    q = 1e-9
+    for dc in (0.0, 0.5, -10.51, 1e6):
+        x = rng.normal(0, 1, (2, 1000)) + dc
+        i, off, g = oracle.float64_to_int64(x, np.full(2, q))
+        assert i.dtype == np.int64 and np.all(g == 1.0 / q)
+        y = oracle.int64_to_float64(i, off, g)
+        assert np.max(np.abs(y - x)) <= 0.5 * q + 8 * np.finfo(np.float64).eps * (abs(dc) + 5)
+    z, off, g = oracle.float64_to_int64(np.zeros((1, 10)))
+    assert np.all(z == 0) and g[0] == 1.0 and off[0] == 0.0
+    i, off, g = oracle.float64_to_int64(rng.normal(0, 1, (1, 100)))  # automatic quanta uses nearly all 63 bits
+    assert 2**61 < np.max(np.abs(i)) < 2**63
+
+
 @pytest.mark.parametrize("level", range(9))
 def test_oracle_encoder_read_by_independent_decoder(oracle, level):
     x = sinusoid_noise_i32(1, 9000, seed=level, amp=2**14)[0]
