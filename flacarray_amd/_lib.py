@@ -14,6 +14,7 @@ SYMBOLS = [
     "encode_i32",
     "encode_i32_threaded",
     "decode_i32",
+    "decode_i64",
     "float32_to_int32",
     "int32_to_float32",
     "fa_encode_workspace_bytes",
@@ -21,6 +22,8 @@ SYMBOLS = [
     "fa_encode_i32_device_finish",
     "fa_decode_i32_device",
     "fa_decode_slices_i32_device",
+    "fa_decode_i64_device",
+    "fa_decode_slices_i64_device",
     "fa_float32_to_int32_device",
     "fa_int32_to_float32_device",
     "fa_profile_enable",
@@ -64,6 +67,8 @@ def lib():
     L.encode_i32_threaded.restype = cint
     L.decode_i32.argtypes = [vp, vp, vp, i64, i64, i64, i64, vp, ctypes.c_bool]
     L.decode_i32.restype = cint
+    L.decode_i64.argtypes = L.decode_i32.argtypes
+    L.decode_i64.restype = cint
     L.float32_to_int32.argtypes = [vp, i64, i64, vp, vp, vp, vp]
     L.float32_to_int32.restype = cint
     L.int32_to_float32.argtypes = [vp, i64, i64, vp, vp, vp]
@@ -78,6 +83,10 @@ def lib():
     L.fa_decode_i32_device.restype = cint
     L.fa_decode_slices_i32_device.argtypes = [vp, i64, vp, vp, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.fa_decode_slices_i32_device.restype = cint
+    L.fa_decode_i64_device.argtypes = L.fa_decode_i32_device.argtypes
+    L.fa_decode_i64_device.restype = cint
+    L.fa_decode_slices_i64_device.argtypes = L.fa_decode_slices_i32_device.argtypes
+    L.fa_decode_slices_i64_device.restype = cint
     L.fa_float32_to_int32_device.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp]
     L.fa_float32_to_int32_device.restype = cint
     L.fa_int32_to_float32_device.argtypes = [vp, i64, i64, vp, vp, vp, vp]

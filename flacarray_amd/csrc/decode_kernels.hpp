@@ -43,6 +43,7 @@ struct StreamMeta {
     int32_t B;    // fixed blocksize from STREAMINFO
     int32_t bps;  // bits per sample from STREAMINFO
     int32_t flags;  // 1 = complete seek table
+    int32_t channels;  // 1 (int32 / float32 arrays) or 2 (int64 / float64: low and high words)
 };
 
 __device__ __forceinline__ uint64_t load_be64(const uint8_t* p) {
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void parse_streams_kernel(const uint8_t* __res
     const uint8_t* p = blob + starts[s];
     const int64_t nb = nbytes[s];
     StreamMeta m;
-    m.first_frame = -1; m.seek_abs = -1; m.end_abs = starts[s] + nb; m.npoints = 0; m.B = 0; m.bps = 0; m.flags = 0;
+    m.first_frame = -1; m.seek_abs = -1; m.end_abs = starts[s] + nb; m.npoints = 0; m.B = 0; m.bps = 0; m.flags = 0; m.channels = 0;
     bool ok = nb >= 42 && p[0] == 'f' && p[1] == 'L' && p[2] == 'a' && p[3] == 'C';
     int64_t off = 4;
     while (ok) {
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(256) void parse_streams_kernel(const uint8_t* __res
             m.B = maxb;
             if (minb != maxb) ok = false;  // variable-blocksize streams are never produced on this path
             m.bps = (((p[off + 12] & 1) << 4) | (p[off + 13] >> 4)) + 1;
+            m.channels = ((p[off + 12] >> 1) & 7) + 1;
         } else if (type == 3) {
             m.seek_abs = starts[s] + off;
             m.npoints = (int32_t)(len / 18);
@@ -97,14 +99,14 @@ __global__ __launch_bounds__(256) void parse_streams_kernel(const uint8_t* __res
 }
 
 __global__ __launch_bounds__(256) void build_frame_table_kernel(const uint8_t* __restrict__ blob, const StreamMeta* __restrict__ meta,
-                                                                int64_t n_stream, int64_t nf, int32_t B, int64_t* __restrict__ ftab,
-                                                                int* __restrict__ err) {
+                                                                int64_t n_stream, int64_t nf, int32_t B, int32_t nch,
+                                                                int64_t* __restrict__ ftab, int* __restrict__ err) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n_stream * nf) return;
     const int64_t s = t / nf, f = t - s * nf;
     const StreamMeta m = meta[s];
-    if (m.first_frame < 0) return;
-    if (m.B != B) { atomicOr(err, kErrDecodeInit); return; }
+    if (m.first_frame < 0) { ftab[t] = -1; return; }
+    if (m.B != B || m.channels != nch) { atomicOr(err, kErrDecodeInit); ftab[t] = -1; return; }
     if (!(m.flags & 1)) { ftab[t] = kFrameUnset; return; }
     const uint8_t* sp = blob + m.seek_abs + 18 * f;
     const uint64_t sn = load_be64(sp), off = load_be64(sp + 8);
@@ -208,16 +210,19 @@ struct BitReader {
     }
 };
 
+__device__ __forceinline__ bool channel_code_ok(int ch, int nch);
+
 struct FrameHeader {
     int bs;
     int bps;
     int ok;
+    int ch;  // channel assignment code
 };
 
 // frame header (RFC 9639 9.1); CRC-8 verified
-__device__ __forceinline__ FrameHeader read_frame_header(BitReader& br, int si_bps) {
+__device__ __forceinline__ FrameHeader read_frame_header(BitReader& br, int si_bps, int nch) {
     FrameHeader h;
-    h.ok = 0; h.bs = 0; h.bps = 0;
+    h.ok = 0; h.bs = 0; h.bps = 0; h.ch = 0;
     uint8_t c8 = 0;
     const uint32_t b01 = br.get(16);
     c8 = crc8_byte(c8, (uint8_t)(b01 >> 8));
@@ -228,7 +233,8 @@ __device__ __forceinline__ FrameHeader read_frame_header(BitReader& br, int si_b
     c8 = crc8_byte(c8, (uint8_t)b2);
     c8 = crc8_byte(c8, (uint8_t)b3);
     const int bsc = (int)(b2 >> 4), src = (int)(b2 & 15), ch = (int)(b3 >> 4), ssc = (int)((b3 >> 1) & 7);
-    if (ch != 0 || (b3 & 1)) return h;
+    if (!channel_code_ok(ch, nch) || (b3 & 1)) return h;
+    h.ch = ch;
     const uint32_t u0 = br.get(8);
     c8 = crc8_byte(c8, (uint8_t)u0);
     int extra = 0;
@@ -280,14 +286,17 @@ struct HeaderBytes {
     uint64_t num;
 };
 
-// frame header from a byte range [p, p + avail) (RFC 9639 9.1); fixed blocksize, mono only
-__device__ __noinline__ HeaderBytes parse_header_bytes(const uint8_t* p, int64_t avail) {
+// frame header from a byte range [p, p + avail) (RFC 9639 9.1); fixed blocksize, mono or stereo
+__device__ __forceinline__ bool channel_code_ok(int ch, int nch) {
+    return (nch == 1) ? (ch == 0) : (ch == 1 || (ch >= 8 && ch <= 10));
+}
+__device__ __noinline__ HeaderBytes parse_header_bytes(const uint8_t* p, int64_t avail, int nch) {
     HeaderBytes h;
     h.ok = 0; h.bs = 0; h.num = 0;
     if (avail < 6) return h;
     if (p[0] != 0xFF || p[1] != 0xF8) return h;
     const int bsc = p[2] >> 4, src = p[2] & 15, ch = p[3] >> 4, ssc = (p[3] >> 1) & 7;
-    if (bsc == 0 || src == 15 || ch != 0 || (p[3] & 1) || ssc == 3) return h;
+    if (bsc == 0 || src == 15 || !channel_code_ok(ch, nch) || (p[3] & 1) || ssc == 3) return h;
     int n = 4;
     const uint32_t u0 = p[n++];
     int extra = 0;
@@ -327,7 +336,7 @@ __global__ __launch_bounds__(256) void scan_sync_kernel(const uint8_t* __restric
                                                         int* __restrict__ sflag) {
     const int64_t s = blockIdx.x;
     const StreamMeta m = meta[s];
-    if (m.first_frame < 0 || (m.flags & 1) || m.B != B) return;
+    if (m.first_frame < 0 || (m.flags & 1) || m.B != B || m.channels < 1 || m.channels > 2) return;
     const int64_t lo = m.first_frame, hi = m.end_abs;
     const int tail_bs = (int)(stream_size - (nf - 1) * (int64_t)B);
     // 16-byte groups on the blob's own 16-byte grid (the blob base is 16-byte aligned)
@@ -356,7 +365,7 @@ __global__ __launch_bounds__(256) void scan_sync_kernel(const uint8_t* __restric
             const int64_t pos = g + i;
             if (pos < lo || pos + 6 > hi) continue;
             if (blob[pos + 1] != 0xF8) continue;
-            const HeaderBytes h = parse_header_bytes(blob + pos, hi - pos);
+            const HeaderBytes h = parse_header_bytes(blob + pos, hi - pos, m.channels);
             if (!h.ok || h.num >= (uint64_t)nf) continue;
             if (h.bs != ((h.num == (uint64_t)(nf - 1)) ? tail_bs : B)) continue;
             const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&ftab[s * nf + (int64_t)h.num]),
@@ -389,7 +398,7 @@ __global__ __launch_bounds__(64) void walk_frames_kernel(const uint8_t* __restri
     const int64_t s = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (s >= n_stream) return;
     const StreamMeta m = meta[s];
-    if (m.first_frame < 0 || (m.flags & 1) || m.B != B) return;
+    if (m.first_frame < 0 || (m.flags & 1) || m.B != B || m.channels < 1 || m.channels > 2) return;
     if (sflag && !sflag[s]) return;  // the sync scan located every frame
     int64_t at = m.first_frame;
     for (int64_t f = 0; f < nf; ++f) {
@@ -397,15 +406,17 @@ __global__ __launch_bounds__(64) void walk_frames_kernel(const uint8_t* __restri
         if (at >= m.end_abs) { atomicOr(err, kErrDecodeProcess); for (int64_t r = f; r < nf; ++r) ftab[s * nf + r] = -1; return; }
         BitReader br;
         br.init(blob, blob + blob_bytes, blob + at);
-        FrameHeader h = read_frame_header(br, m.bps);
+        FrameHeader h = read_frame_header(br, m.bps, m.channels);
         bool ok = h.ok;
-        if (ok) {
+        for (int chn = 0; ok && chn < m.channels; ++chn) {
+            // a side channel (left/side and mid/side: channel 1; side/right: channel 0) has one more bit
+            const int fbps = h.bps + (((chn == 1 && (h.ch == 8 || h.ch == 10)) || (chn == 0 && h.ch == 9)) ? 1 : 0);
             const uint32_t sf = br.get(8);
             int tc = (int)((sf >> 1) & 0x3f);
             int wasted = 0;
             if (sf & 0x80) ok = false;
             if (sf & 1) wasted = (int)br.unary() + 1;
-            const int bps = h.bps - wasted;
+            const int bps = fbps - wasted;
             int order = 0;
             bool pred = false;
             if (bps <= 0) ok = false;
@@ -480,6 +491,10 @@ struct DecodeArgs {
     const float* offsets;   // per stream
     const float* gains;
     int* err;
+    // two-channel arrays (NCH == 2): out_i32 is then the task-local planar image
+    uint32_t* hibits;   // [n_tasks][2][hib_words] bit 32 of every sample
+    int32_t* assign;    // [n_tasks] channel assignment once both subframes are decoded, else -1
+    int32_t hib_words;  // ceil(B / 32)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -674,8 +689,13 @@ __device__ __noinline__ BitsRet slow_sample(const uint8_t* cbase, const uint8_t*
 // left for a later pass (flag word); tasks with order <= MO_DONE were done by an earlier one.
 // F32: dequantised float32 output (needs per-row offset / 1/gain descriptors in LDS); the int32
 // variant leaves them out, which is what lets a ninth wave fit on a CU.
-template <int MO, int MO_DONE, bool F32>
+// NCH = 2: two-channel frames (the reference's int64 / float64 arrays: low and high words).  A lane
+// decodes its frame's two subframes one after the other into a task-local planar image
+// tmp[(task * 2 + channel) * B + sample] (low 32 bits) plus one bit per sample for bit 32 (side
+// channels carry 33 bits); combine_channels_kernel undoes the stereo decorrelation and writes int64.
+template <int MO, int MO_DONE, bool F32, int NCH>
 __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* flags) {
+    static_assert(NCH == 1 || (kTileW == 32 && !F32), "two-channel variant: 32-sample tiles, integer output");
     __shared__ __attribute__((aligned(16))) uint32_t rings[kDecRingWords * kLaneStride];
     __shared__ __attribute__((aligned(16))) int32_t tile[kTileW * kLaneStride];  // sample t of lane l at t*64 + (l ^ 8*(t>>2))
 #ifdef FA_DEC_LDS_PAD
@@ -705,25 +725,18 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
         }
     }
     const int64_t fstart = f * (int64_t)a.B;
-    int lo = 0, hi = 0;  // valid sample range inside this frame
-    int bs = 0;
-    int mode = 3;  // 0 const, 1 verbatim, 2 predictive, 3 idle
-    int order = 0, bps = 0, wasted = 0;
-    int32_t cval = 0;
-    double scale = 1.0;
-    double c[MO], h[MO];
-#pragma unroll
-    for (int j = 0; j < MO; ++j) { c[j] = 0.0; h[j] = 0.0; }
-    int plen = 4, esc = 15, ps = 0, pleft = 0, k = 0, escw = -1;
     // reader state
     const uint8_t* cbase = a.blob;
     const uint8_t* const lim16 = reinterpret_cast<const uint8_t*>((reinterpret_cast<uintptr_t>(a.blob + a.blob_bytes) + 15) & ~(uintptr_t)15);
     uint32_t bitpos = 0, next_chunk = 0x00400000u;  // idle lanes never refill
 
+    // ---- frame header (RFC 9639 9.1), CRC-8 verified ----
+    bool bad = false;
+    bool task_live = has_task;  // false: nothing (more) to decode for this lane
+    int fbs = 0, fbps = 0, ch_assign = 0, si_bps = 0;
     if (has_task) {
-        bool bad = false;
-        bool is_lpc = false;
         const StreamMeta m = a.meta[s];
+        si_bps = m.bps;
         const int64_t at = a.ftab[s * a.nf + f];
         if (m.first_frame < 0 || at < 0) bad = true;
         else {
@@ -734,8 +747,6 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
             ring_load_chunk(cbase, lim16, ring, 0);
             ring_load_chunk(cbase, lim16, ring, 1);
             next_chunk = 2;
-            // ---- frame header (RFC 9639 9.1), CRC-8 verified ----
-            int fbs = 0, fbps = 0;
             {
                 uint8_t c8 = 0;
                 const uint32_t w = FA_GET(32);
@@ -746,7 +757,8 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
                 if ((w >> 16) != 0xFFF8) bad = true;  // sync, reserved 0, fixed blocksize
                 const uint32_t b2 = (w >> 8) & 0xff, b3 = w & 0xff;
                 const int bsc = (int)(b2 >> 4), src = (int)(b2 & 15), ch = (int)(b3 >> 4), ssc = (int)((b3 >> 1) & 7);
-                if (ch != 0 || (b3 & 1)) bad = true;
+                if (!channel_code_ok(ch, NCH) || (b3 & 1)) bad = true;
+                ch_assign = ch;
                 const uint32_t u0 = FA_GET(8);
                 c8 = crc8_byte(c8, (uint8_t)u0);
                 int extra = 0;
@@ -767,7 +779,7 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
                 else if (src == 15) bad = true;
                 if (FA_GET(8) != c8) bad = true;
                 switch (ssc) {
-                    case 0: fbps = m.bps; break;
+                    case 0: fbps = si_bps; break;
                     case 1: fbps = 8; break;
                     case 2: fbps = 12; break;
                     case 4: fbps = 16; break;
@@ -780,38 +792,87 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
             int64_t expect = a.stream_size - fstart;
             if (expect > a.B) expect = a.B;
             if (fbs != (int)expect) bad = true;
-            if (!bad) {
-                bs = fbs;
-                const uint32_t sf = FA_GET(8);
-                const int tc = (int)((sf >> 1) & 0x3f);
-                if (sf & 0x80) bad = true;
-                if (sf & 1) wasted = (int)FA_UNARY() + 1;
-                bps = fbps - wasted;
-                if (bps <= 0 || bps > 32) bad = true;
-                else if (tc == 0) { mode = 0; cval = FA_GETS(bps); }
-                else if (tc == 1) { mode = 1; }
-                else if (tc >= 8 && tc <= 12) { mode = 2; order = tc - 8; }
-                else if (tc >= 32) { mode = 2; order = (tc & 31) + 1; is_lpc = true; }
-                else bad = true;
-                if (order > bs) bad = true;
+        }
+        if constexpr (NCH == 2) {
+            if (a.assign[task] >= 0) task_live = false;  // completed by an earlier (shallower) pass
+        }
+        if (bad) { task_live = false; atomicOr(a.err, kErrDecodeProcess); }
+    }
+    const bool out_aligned = ((reinterpret_cast<uintptr_t>(a.out_f32 ? (const void*)a.out_f32 : (const void*)a.out_i32) & 15) == 0);
+
+    // read `n` (1..33) bits as a signed value; 33-bit values (side channels) only exist for NCH == 2
+    auto get_wide = [&](int n) __attribute__((always_inline)) -> double {
+        if constexpr (NCH == 2) {
+            if (n > 32) {
+                const uint32_t top = FA_GET(1);
+                const uint32_t low = FA_GET(32);
+                return (double)low - (top ? 4294967296.0 : 0.0);
             }
+        }
+        return (double)FA_GETS(n);
+    };
+    // low 32 bits of an exact integer in (-2^32, 2^32), as int32
+    auto wrap32 = [&](double v) __attribute__((always_inline)) -> int32_t {
+        if constexpr (NCH == 2) {
+            if (v >= 2147483648.0) v -= 4294967296.0;
+            else if (v < -2147483648.0) v += 4294967296.0;
+        }
+        return (int32_t)v;
+    };
+
+#pragma unroll 1
+    for (int chn = 0; chn < NCH; ++chn) {
+    int lo = 0, hi = 0;  // valid sample range inside this frame
+    int bs = 0;
+    int mode = 3;  // 0 const, 1 verbatim, 2 predictive, 3 idle
+    int order = 0, bps = 0, wasted = 0;
+    double cval = 0.0;
+    double scale = 1.0;
+    double c[MO], h[MO];
+#pragma unroll
+    for (int j = 0; j < MO; ++j) { c[j] = 0.0; h[j] = 0.0; }
+    int plen = 4, esc = 15, ps = 0, pleft = 0, k = 0, escw = -1;
+    uint32_t hbw = 0;  // NCH == 2: bit 32 (the sign) of the samples of the current tile
+
+    if (task_live) {
+        bool is_lpc = false;
+        {
+            bs = fbs;
+            const uint32_t sf = FA_GET(8);
+            const int tc = (int)((sf >> 1) & 0x3f);
+            if (sf & 0x80) bad = true;
+            if (sf & 1) wasted = (int)FA_UNARY() + 1;
+            // a side channel (left/side, mid/side: channel 1; side/right: channel 0) has one more bit
+            const int side = (NCH == 2 && ((chn == 1 && (ch_assign == 8 || ch_assign == 10)) || (chn == 0 && ch_assign == 9))) ? 1 : 0;
+            bps = fbps + side - wasted;
+            if (bps <= 0 || bps > 32 + side) bad = true;
+            else if (tc == 0) { mode = 0; cval = get_wide(bps); }
+            else if (tc == 1) { mode = 1; }
+            else if (tc >= 8 && tc <= 12) { mode = 2; order = tc - 8; }
+            else if (tc >= 32) { mode = 2; order = (tc & 31) + 1; is_lpc = true; }
+            else bad = true;
+            if (order > bs) bad = true;
         }
         if (!bad) {
             if (order > MO) {  // a later pass with a deeper history decodes this frame
                 atomicOr(flags, order > 16 ? kFlagNeed32 : kFlagNeed16);
                 mode = 3;
-            } else if (order <= MO_DONE) {
+                task_live = false;
+            } else if (NCH == 1 && order <= MO_DONE) {
                 mode = 3;  // decoded by an earlier pass
             }
         }
         if (!bad && mode == 2) {
             // ---- warm-up samples, predictor description, residual header (serial per lane) ----
             for (int i = 0; i < order; ++i) {
-                const int32_t x = FA_GETS(bps);
-                if (i < kTileW) tile[i * kLaneStride + (lane ^ ((i >> 2) * kTileSwz))] = (int32_t)((uint32_t)x << wasted);
+                const double x = get_wide(bps);
+                if (i < kTileW) {
+                    tile[i * kLaneStride + (lane ^ ((i >> 2) * kTileSwz))] = (int32_t)((uint32_t)wrap32(x) << wasted);
+                    if constexpr (NCH == 2) hbw |= (x < 0.0) ? (1u << i) : 0u;
+                }
 #pragma unroll
                 for (int jj = 0; jj < MO; ++jj)
-                    if (jj == (i % MO)) h[jj] = (double)x;
+                    if (jj == (i % MO)) h[jj] = x;
             }
             if (is_lpc) {
                 const int prec = (int)FA_GET(4) + 1;
@@ -838,7 +899,7 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
             if (method > 1 || (po > 0 && (ps << po) != bs) || ps < order) bad = true;
             pleft = -order;  // partition 0 is short by `order`
         }
-        if (bad) { mode = 3; atomicOr(a.err, kErrDecodeProcess); }
+        if (bad) { mode = 3; task_live = false; atomicOr(a.err, kErrDecodeProcess); }
         if (mode != 3) {
             int64_t l = sl_first - fstart, h2 = sl_last - fstart;
             if (l < 0) l = 0;
@@ -854,7 +915,7 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
     if (mode == 3) { bs = 0x7fffffff; next_chunk = 0x00400000u; bitpos = 0; order = 0; escw = 0; pleft = 0x7fffffff; ps = 0; }
     if (mode == 0) {
 #pragma unroll
-        for (int j = 0; j < MO; ++j) { c[j] = 0.0; h[j] = (double)cval; }
+        for (int j = 0; j < MO; ++j) { c[j] = 0.0; h[j] = cval; }
         c[0] = 1.0; scale = 1.0; order = 0; escw = 0; pleft = 0x7fffffff;
     }
     if (mode == 1) {
@@ -871,7 +932,11 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
     }
     bs_min = __builtin_amdgcn_readfirstlane(bs_min);
     // row descriptors for the cooperative store
-    row_out[lane] = out_off + (fstart - sl_first);  // output element index of frame sample 0
+    __builtin_amdgcn_wave_barrier();
+    int64_t row0;  // output element index of frame sample 0
+    if constexpr (NCH == 2) row0 = (task * 2 + chn) * (int64_t)a.B;
+    else row0 = out_off + (fstart - sl_first);
+    row_out[lane] = row0;
     row_rng[lane] = make_int2(lo, hi);
     if constexpr (F32) {
         float og = 0.0f, cf = 1.0f;
@@ -881,11 +946,10 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
         }
         row_fg[lane] = make_float2(og, cf);
     }
-    const bool out_aligned = ((reinterpret_cast<uintptr_t>(a.out_f32 ? (const void*)a.out_f32 : (const void*)a.out_i32) & 15) == 0);
     // a tile that lies inside every row's valid range and whose rows are 16-byte aligned in the
     // output is stored without per-element tests (the common case: whole frames of whole streams)
     int lo_max = lo, hi_min = hi;
-    bool row_al = out_aligned && (((out_off + (fstart - sl_first)) & 3) == 0);
+    bool row_al = out_aligned && ((row0 & 3) == 0);
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const int o1 = __shfl_xor(lo_max, off, 64), o2 = __shfl_xor(hi_min, off, 64);
@@ -946,11 +1010,19 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
             const uint32_t uu = ((uint32_t)z << k) | low;
             int32_t r = (int32_t)(uu >> 1) ^ -(int32_t)(uu & 1);
             uint32_t nbp = bitpos + (uint32_t)(z + 1 + k);
+            double radd = 0.0;  // NCH == 2: what a 33-bit VERBATIM sample adds to its low word
             if (__builtin_expect(!__all(fastok), 0)) {
                 if (!fastok) {
                     if (escw == 0) {
                         r = 0;
                         nbp = bitpos;
+                    } else if (NCH == 2 && escw > 32) {
+                        const BitsRet t1 = slow_get(cbase, lim16, ring, bitpos, next_chunk, 1);
+                        const BitsRet t2 = slow_get(cbase, lim16, ring, t1.bitpos, t1.next_chunk, 32);
+                        r = (int32_t)t2.val;
+                        radd = ((t2.val >> 31) ? 4294967296.0 : 0.0) - (t1.val ? 4294967296.0 : 0.0);
+                        nbp = t2.bitpos;
+                        next_chunk = ring_ensure(cbase, lim16, ring, t2.bitpos, t2.next_chunk);
                     } else {
                         const BitsRet sr = slow_sample(cbase, lim16, ring, bitpos, next_chunk, k, escw);
                         r = (int32_t)sr.val;
@@ -967,18 +1039,27 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
             double sum = 0.0;
 #pragma unroll
             for (int j = MO - 1; j >= 0; --j) sum = __builtin_fma(c[j], h[(u + MO - 1 - j) % MO], sum);
-            const double xd = (double)r + fa_floor(sum * scale);
+            double xd = (double)r + fa_floor(sum * scale);
+            if constexpr (NCH == 2) {
+                xd += radd;
+                hbw |= (xd < 0.0) ? (1u << (i & 31)) : 0u;
+            }
             h[u % MO] = xd;
-            tile[(i & (kTileW - 1)) * kLaneStride + (lane ^ (((i & (kTileW - 1)) >> 2) * kTileSwz))] = (int32_t)((uint32_t)(int32_t)xd << wasted);
+            tile[(i & (kTileW - 1)) * kLaneStride + (lane ^ (((i & (kTileW - 1)) >> 2) * kTileSwz))] = (int32_t)((uint32_t)wrap32(xd) << wasted);
         } else if constexpr (GUARD) {
             // warm-up sample 16..31 (orders above 16): its value sits in the history
-            if (i < bs && i >= kTileW) tile[(i & (kTileW - 1)) * kLaneStride + (lane ^ (((i & (kTileW - 1)) >> 2) * kTileSwz))] = (int32_t)((uint32_t)(int32_t)h[u % MO] << wasted);
+            if (i < bs && i >= kTileW) tile[(i & (kTileW - 1)) * kLaneStride + (lane ^ (((i & (kTileW - 1)) >> 2) * kTileSwz))] = (int32_t)((uint32_t)wrap32(h[u % MO]) << wasted);
         }
     };
 
     // cooperative store of the tile: (64 / kTileG) rows x kTileW samples per pass, 16 bytes per lane
     auto flush_tile = [&](int tbase) __attribute__((always_inline)) {
         __builtin_amdgcn_wave_barrier();
+        if constexpr (NCH == 2) {
+            // bit 32 of this lane's 32 samples (tiles are 32 samples wide)
+            if (tbase < hi && tbase + kTileW > lo) a.hibits[(task * 2 + chn) * (int64_t)a.hib_words + (tbase >> 5)] = hbw;
+            hbw = 0;
+        }
         constexpr int kRowsPerPass = 64 / kTileG;
 #ifndef FA_NO_FASTFLUSH
         if (!F32 && all_al && tbase >= lo_max && tbase + kTileW <= hi_min) {
@@ -1068,6 +1149,67 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
         for (int i0 = g_lo; i0 < g_hi; i0 += MACRO) macro_step(std::true_type{}, i0);
         if (pass == 0)
             for (int i0 = main_lo; i0 < main_hi; i0 += MACRO) macro_step(std::false_type{}, i0);
+    }
+    }  // channel loop
+    if constexpr (NCH == 2) {
+        if (has_task && task_live) a.assign[task] = ch_assign;  // both subframes decoded
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K8 (two-channel arrays): planar (low words + bit 32) -> int64 or float64.  One workgroup per
+// task (stream row x frame).  Undoes left/side, side/right and mid/side (RFC 9639 9.1.3); the
+// reference's int64 value is (channel 1 << 32) | (channel 0 as unsigned) (utils.c:96-123), and the
+// optional float64 restore is offsets + (1 / gains) * value (int64_to_float64, utils.c:329-348).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void combine_channels_kernel(DecodeArgs a, int64_t* __restrict__ out_i64,
+                                                               double* __restrict__ out_f64, const double* __restrict__ offsets64,
+                                                               const double* __restrict__ gains64) {
+    const int64_t task = blockIdx.x;
+    int64_t s, f, sl_first, sl_last, out_off;
+    if (a.task_stream) {
+        s = a.task_stream[task]; f = a.task_frame[task];
+        sl_first = a.task_first[task]; sl_last = a.task_last[task];
+        out_off = a.task_out_off[task];
+    } else {
+        s = task / a.nfr; f = a.f0 + (task - s * a.nfr);
+        sl_first = a.first; sl_last = a.first + a.n_decode;
+        out_off = s * a.n_decode;
+    }
+    const int asg = a.assign[task];
+    if (asg < 0) {
+        if (threadIdx.x == 0) atomicOr(a.err, kErrDecodeProcess);
+        return;
+    }
+    const int64_t fstart = f * (int64_t)a.B;
+    int64_t bs = a.stream_size - fstart;
+    if (bs > a.B) bs = a.B;
+    int64_t lo = sl_first - fstart, hi = sl_last - fstart;
+    if (lo < 0) lo = 0;
+    if (hi > bs) hi = bs;
+    const int32_t* t0 = a.out_i32 + (task * 2 + 0) * (int64_t)a.B;
+    const int32_t* t1 = a.out_i32 + (task * 2 + 1) * (int64_t)a.B;
+    const uint32_t* h0 = a.hibits + (task * 2 + 0) * (int64_t)a.hib_words;
+    const uint32_t* h1 = a.hibits + (task * 2 + 1) * (int64_t)a.hib_words;
+    double off = 0.0, coeff = 1.0;
+    if (out_f64) { off = offsets64[s]; coeff = 1.0 / gains64[s]; }
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        // 33-bit two's complement: low word plus bit 32, which is also the sign
+        const int64_t c0 = (int64_t)(uint64_t)(uint32_t)t0[i] | (((h0[i >> 5] >> (i & 31)) & 1u) ? (int64_t)0xFFFFFFFF00000000LL : 0);
+        const int64_t c1 = (int64_t)(uint64_t)(uint32_t)t1[i] | (((h1[i >> 5] >> (i & 31)) & 1u) ? (int64_t)0xFFFFFFFF00000000LL : 0);
+        int64_t L, R;
+        if (asg == 1) { L = c0; R = c1; }
+        else if (asg == 8) { L = c0; R = c0 - c1; }
+        else if (asg == 9) { R = c1; L = c0 + c1; }
+        else {
+            const int64_t mid = (int64_t)((uint64_t)c0 << 1) | (c1 & 1);
+            L = (mid + c1) >> 1;
+            R = (mid - c1) >> 1;
+        }
+        const int64_t v = (int64_t)(((uint64_t)R << 32) | (uint64_t)(uint32_t)L);
+        const int64_t o = out_off + (fstart - sl_first) + i;
+        if (out_f64) out_f64[o] = off + coeff * (double)v;
+        else out_i64[o] = v;
     }
 }
 

@@ -57,8 +57,8 @@ void prof_end(int k, hipStream_t st) {
 struct DeviceState {
     std::map<int, float*> windows;  // blocksize -> device tukey(0.5) table
     uint16_t* crc_tab = nullptr;
-    void* scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void* scratch[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 std::map<int, DeviceState> g_dev;
 
@@ -191,7 +191,8 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
                        int64_t n_stream, int64_t stream_size, int64_t first_decode, int64_t n_decode, int64_t n_slices,
                        const int64_t* slice_stream, const int64_t* slice_first, const int64_t* slice_count,
                        const int64_t* out_offset, int32_t* d_out_i32, float* d_out_f32, const float* d_offsets,
-                       const float* d_gains, hipStream_t st) {
+                       const float* d_gains, hipStream_t st, int nch = 1, int64_t* d_out_i64 = nullptr, double* d_out_f64 = nullptr,
+                       const double* d_offsets64 = nullptr, const double* d_gains64 = nullptr) {
     // the decode kernel issues 16-byte loads relative to the blob base: realign if necessary
     if (reinterpret_cast<uintptr_t>(d_bytes) & 15) {
         void* al = nullptr;
@@ -219,6 +220,7 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
     FA_HIP_TRY(hipStreamSynchronize(st));
     if (h_err[0]) return h_err[0];
     const int32_t B = m0.B;
+    if (m0.channels != nch) return FA_ERROR_DECODE_INIT;  // an int32 stream read as int64 or the reverse
     if (B <= 0 || B > 65535) return FA_ERROR_DECODE_INIT;
     if (B > kMaxBlock * 16) return FA_ERROR_DECODE_INIT;
     const int64_t nf = (stream_size + B - 1) / B;
@@ -230,7 +232,7 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
     int64_t* d_ftab = reinterpret_cast<int64_t*>(pt);
     const int64_t nt = n_stream * nf;
     hipLaunchKernelGGL(build_frame_table_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, d_bytes, d_meta, n_stream,
-                       nf, B, d_ftab, d_err);
+                       nf, B, nch, d_ftab, d_err);
     if (h_err[2] > 0) {
         const bool scan = (std::getenv("FLACARRAY_HIP_NO_SYNC_SCAN") == nullptr);  // diagnostic: force the serial walk
         if (scan) {
@@ -291,19 +293,51 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
     if (a.B > kMaxBlock * 16) return FA_ERROR_DECODE_INIT;
     const unsigned nblk = (unsigned)((a.n_tasks + 63) / 64);
     const bool f32 = (d_out_f32 != nullptr);
+    if (nch == 2) {
+        // two-channel arrays: task-local planar image (low words), bit 32 of every sample, task status
+        a.hib_words = (a.B + 31) / 32;
+        const size_t tmp_b = align_up((size_t)a.n_tasks * 2 * (size_t)a.B * 4, 256);
+        const size_t hib_b = align_up((size_t)a.n_tasks * 2 * (size_t)a.hib_words * 4, 256);
+        const size_t asg_b = align_up((size_t)a.n_tasks * 4, 256);
+        void* p8 = nullptr;
+        rc = get_scratch(8, tmp_b + hib_b + asg_b, &p8);
+        if (rc) return rc;
+        a.out_i32 = reinterpret_cast<int32_t*>(p8);
+        a.out_f32 = nullptr;
+        a.hibits = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(p8) + tmp_b);
+        a.assign = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(p8) + tmp_b + hib_b);
+        FA_HIP_TRY(hipMemsetAsync(a.assign, 0xFF, (size_t)a.n_tasks * 4, st));
+        prof_begin(2, st);
+        hipLaunchKernelGGL((decode_frames_kernel<8, -1, false, 2>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
+        prof_end(2, st);
+        FA_HIP_TRY(hipMemcpyAsync(h_err, d_err, 16, hipMemcpyDeviceToHost, st));
+        FA_HIP_TRY(hipStreamSynchronize(st));
+        if (h_err[1] & kFlagNeed16) hipLaunchKernelGGL((decode_frames_kernel<16, 8, false, 2>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
+        if (h_err[1]) {  // a frame left over by the 16-deep pass raises the flag again
+            FA_HIP_TRY(hipMemcpyAsync(h_err, d_err, 16, hipMemcpyDeviceToHost, st));
+            FA_HIP_TRY(hipStreamSynchronize(st));
+        }
+        if (h_err[1] & kFlagNeed32) hipLaunchKernelGGL((decode_frames_kernel<32, 16, false, 2>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
+        hipLaunchKernelGGL(combine_channels_kernel, dim3((unsigned)a.n_tasks), dim3(256), 0, st, a, d_out_i64, d_out_f64, d_offsets64,
+                           d_gains64);
+        FA_HIP_TRY(hipMemcpyAsync(h_err, d_err, 16, hipMemcpyDeviceToHost, st));
+        FA_HIP_TRY(hipStreamSynchronize(st));
+        FA_HIP_TRY(hipGetLastError());
+        return h_err[0];
+    }
     prof_begin(2, st);
-    if (f32) hipLaunchKernelGGL((decode_frames_kernel<8, -1, true>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
-    else hipLaunchKernelGGL((decode_frames_kernel<8, -1, false>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
+    if (f32) hipLaunchKernelGGL((decode_frames_kernel<8, -1, true, 1>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
+    else hipLaunchKernelGGL((decode_frames_kernel<8, -1, false, 1>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
     prof_end(2, st);
     FA_HIP_TRY(hipMemcpyAsync(h_err, d_err, 16, hipMemcpyDeviceToHost, st));
     FA_HIP_TRY(hipStreamSynchronize(st));
     if (h_err[1] & kFlagNeed16) {
-        if (f32) hipLaunchKernelGGL((decode_frames_kernel<16, 8, true>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
-        else hipLaunchKernelGGL((decode_frames_kernel<16, 8, false>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
+        if (f32) hipLaunchKernelGGL((decode_frames_kernel<16, 8, true, 1>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
+        else hipLaunchKernelGGL((decode_frames_kernel<16, 8, false, 1>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
     }
     if (h_err[1] & kFlagNeed32) {
-        if (f32) hipLaunchKernelGGL((decode_frames_kernel<32, 16, true>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
-        else hipLaunchKernelGGL((decode_frames_kernel<32, 16, false>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
+        if (f32) hipLaunchKernelGGL((decode_frames_kernel<32, 16, true, 1>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
+        else hipLaunchKernelGGL((decode_frames_kernel<32, 16, false, 1>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
     }
     if (h_err[1]) {
         FA_HIP_TRY(hipMemcpyAsync(h_err, d_err, 16, hipMemcpyDeviceToHost, st));
@@ -485,6 +519,37 @@ int fa_decode_slices_i32_device(const unsigned char* d_bytes, int64_t n_bytes, c
                               reinterpret_cast<hipStream_t>(stream));
 }
 
+int fa_decode_i64_device(const unsigned char* d_bytes, int64_t n_bytes, const int64_t* d_starts,
+                         const int64_t* d_nbytes, int64_t n_stream, int64_t stream_size, int64_t first_sample,
+                         int64_t last_sample, int64_t* d_out_i64, double* d_out_f64, const double* d_offsets,
+                         const double* d_gains, void* stream) {
+    if (n_stream <= 0) return FA_ERROR_ZERO_NSTREAM;
+    if (stream_size <= 0) return FA_ERROR_DECODE_STREAMSIZE;
+    if ((d_out_i64 == nullptr) == (d_out_f64 == nullptr)) return FA_ERROR_CONVERT_TYPE;
+    if (d_out_f64 && (!d_offsets || !d_gains)) return FA_ERROR_CONVERT_TYPE;
+    int64_t first_decode, n_decode;
+    int rc = validate_range(stream_size, first_sample, last_sample, &first_decode, &n_decode);
+    if (rc) return rc;
+    return decode_device_impl(d_bytes, n_bytes, d_starts, d_nbytes, n_stream, stream_size, first_decode, n_decode, -1, nullptr,
+                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<hipStream_t>(stream), 2,
+                              d_out_i64, d_out_f64, d_offsets, d_gains);
+}
+
+int fa_decode_slices_i64_device(const unsigned char* d_bytes, int64_t n_bytes, const int64_t* d_starts,
+                                const int64_t* d_nbytes, int64_t n_stream, int64_t stream_size, int64_t n_slices,
+                                const int64_t* slice_stream, const int64_t* slice_first, const int64_t* slice_count,
+                                const int64_t* out_offset, int64_t* d_out_i64, double* d_out_f64,
+                                const double* d_offsets, const double* d_gains, void* stream) {
+    if (n_stream <= 0) return FA_ERROR_ZERO_NSTREAM;
+    if (stream_size <= 0) return FA_ERROR_DECODE_STREAMSIZE;
+    if (n_slices <= 0) return FA_ERROR_NONE;
+    if ((d_out_i64 == nullptr) == (d_out_f64 == nullptr)) return FA_ERROR_CONVERT_TYPE;
+    if (d_out_f64 && (!d_offsets || !d_gains)) return FA_ERROR_CONVERT_TYPE;
+    return decode_device_impl(d_bytes, n_bytes, d_starts, d_nbytes, n_stream, stream_size, 0, 0, n_slices, slice_stream,
+                              slice_first, slice_count, out_offset, nullptr, nullptr, nullptr, nullptr,
+                              reinterpret_cast<hipStream_t>(stream), 2, d_out_i64, d_out_f64, d_offsets, d_gains);
+}
+
 int fa_float32_to_int32_device(const float* d_input, int64_t n_stream, int64_t stream_size, const float* d_quanta,
                                int32_t* d_output, float* d_offsets, float* d_gains, void* stream) {
     if (n_stream <= 0) return FA_ERROR_ZERO_NSTREAM;
@@ -598,9 +663,10 @@ int encode_i32_threaded(int32_t* const data, int64_t n_stream, int64_t stream_si
     return encode_host(data, n_stream, stream_size, level, n_bytes, starts, bytes);
 }
 
-int decode_i32(unsigned char* const bytes, int64_t* const starts, int64_t* const nbytes, int64_t n_stream,
-               int64_t stream_size, int64_t first_sample, int64_t last_sample, int32_t* data, bool use_threads) {
-    (void)use_threads;
+static int decode_host(const unsigned char* bytes, const int64_t* starts, const int64_t* nbytes, int64_t n_stream,
+                       int64_t stream_size, int64_t first_sample, int64_t last_sample, void* data_v, int nch) {
+    const size_t esz = 4 * (size_t)nch;  // bytes per decoded sample
+    unsigned char* data = reinterpret_cast<unsigned char*>(data_v);
     int64_t first_decode, n_decode;
     int rc = validate_range(stream_size, first_sample, last_sample, &first_decode, &n_decode);  // decompress.c:209-222
     if (rc) return rc;
@@ -608,7 +674,7 @@ int decode_i32(unsigned char* const bytes, int64_t* const starts, int64_t* const
     if (fa_device_count() <= 0) return FA_ERROR_DEVICE;
     size_t free_b = 0, total_b = 0;
     FA_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const size_t per_stream = (size_t)n_decode * 4 + (size_t)stream_size * 5 + 65536;
+    const size_t per_stream = (size_t)n_decode * esz * (nch == 2 ? 2 : 1) + (size_t)stream_size * (esz + 1) + 65536;
     int64_t chunk = (int64_t)((free_b / 10 * 7) / per_stream);
     if (chunk < 1) chunk = 1;
     if (chunk > n_stream) chunk = n_stream;
@@ -627,19 +693,36 @@ int decode_i32(unsigned char* const bytes, int64_t* const starts, int64_t* const
         void *d_blob = nullptr, *d_aux = nullptr, *d_out = nullptr;
         if ((err = get_scratch(0, (size_t)(hi - lo) + 256, &d_blob))) break;
         if ((err = get_scratch(4, (size_t)ns * 16 + 512, &d_aux))) break;
-        if ((err = get_scratch(5, (size_t)ns * (size_t)n_decode * 4 + 256, &d_out))) break;
+        if ((err = get_scratch(5, (size_t)ns * (size_t)n_decode * esz + 256, &d_out))) break;
         int64_t* d_starts = reinterpret_cast<int64_t*>(d_aux);
         int64_t* d_nb = d_starts + ns;
         if (hipMemcpy(d_blob, bytes + lo, (size_t)(hi - lo), hipMemcpyHostToDevice) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
         if (hipMemcpy(d_starts, st_rel.data(), (size_t)ns * 8, hipMemcpyHostToDevice) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
         if (hipMemcpy(d_nb, nbytes + s0, (size_t)ns * 8, hipMemcpyHostToDevice) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
-        err = decode_device_impl(reinterpret_cast<const unsigned char*>(d_blob), hi - lo, d_starts, d_nb, ns, stream_size, first_decode,
-                                 n_decode, -1, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<int32_t*>(d_out), nullptr, nullptr,
-                                 nullptr, nullptr);
+        if (nch == 1)
+            err = decode_device_impl(reinterpret_cast<const unsigned char*>(d_blob), hi - lo, d_starts, d_nb, ns, stream_size,
+                                     first_decode, n_decode, -1, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<int32_t*>(d_out),
+                                     nullptr, nullptr, nullptr, nullptr);
+        else
+            err = decode_device_impl(reinterpret_cast<const unsigned char*>(d_blob), hi - lo, d_starts, d_nb, ns, stream_size,
+                                     first_decode, n_decode, -1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                     nullptr, 2, reinterpret_cast<int64_t*>(d_out), nullptr, nullptr, nullptr);
         if (err) break;
-        if (hipMemcpy(data + s0 * n_decode, d_out, (size_t)ns * (size_t)n_decode * 4, hipMemcpyDeviceToHost) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
+        if (hipMemcpy(data + (size_t)s0 * (size_t)n_decode * esz, d_out, (size_t)ns * (size_t)n_decode * esz, hipMemcpyDeviceToHost) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
     }
     return err;
+}
+
+int decode_i32(unsigned char* const bytes, int64_t* const starts, int64_t* const nbytes, int64_t n_stream,
+               int64_t stream_size, int64_t first_sample, int64_t last_sample, int32_t* data, bool use_threads) {
+    (void)use_threads;
+    return decode_host(bytes, starts, nbytes, n_stream, stream_size, first_sample, last_sample, data, 1);
+}
+
+int decode_i64(unsigned char* const bytes, int64_t* const starts, int64_t* const nbytes, int64_t n_stream,
+               int64_t stream_size, int64_t first_sample, int64_t last_sample, int64_t* data, bool use_threads) {
+    (void)use_threads;
+    return decode_host(bytes, starts, nbytes, n_stream, stream_size, first_sample, last_sample, data, 2);
 }
 
 int float32_to_int32(float const* input, int64_t n_stream, int64_t stream_size, float const* quanta, int32_t* output,

@@ -96,7 +96,7 @@ def wrap_encode_i32_threaded(flatdata, n_stream, stream_size, level):
     return _wrap_encode(_lib.lib().encode_i32_threaded, flatdata, n_stream, stream_size, level)
 
 
-def wrap_decode_i32(compressed, starts, nbytes, n_stream, stream_size, first_sample, last_sample, use_threads):
+def wrap_decode_i32(compressed, starts, nbytes, n_stream, stream_size, first_sample, last_sample, use_threads, _i64=False):
     """libflacarray.pyx:597-653"""
     _lib.require_device()
     n_decode = stream_size
@@ -105,8 +105,8 @@ def wrap_decode_i32(compressed, starts, nbytes, n_stream, stream_size, first_sam
     compressed = np.ascontiguousarray(compressed, dtype=np.uint8)
     starts = np.ascontiguousarray(starts, dtype=np.int64)
     nbytes = np.ascontiguousarray(nbytes, dtype=np.int64)
-    output = np.empty(max(n_stream * n_decode, 0), dtype=flac_i32_dtype)
-    errcode = _lib.lib().decode_i32(
+    output = np.empty(max(n_stream * n_decode, 0), dtype=flac_i64_dtype if _i64 else flac_i32_dtype)
+    errcode = (_lib.lib().decode_i64 if _i64 else _lib.lib().decode_i32)(
         _ptr(compressed), _ptr(starts), _ptr(nbytes), n_stream, stream_size, first_sample, last_sample, _ptr(output),
         bool(use_threads),
     )
@@ -119,7 +119,12 @@ def _no_i64(*args, **kwargs):
     raise NotImplementedError(_NOT_I64)
 
 
-wrap_encode_i64 = wrap_encode_i64_threaded = wrap_decode_i64 = _no_i64
+def wrap_decode_i64(compressed, starts, nbytes, n_stream, stream_size, first_sample, last_sample, use_threads):
+    """libflacarray.pyx:656-710"""
+    return wrap_decode_i32(compressed, starts, nbytes, n_stream, stream_size, first_sample, last_sample, use_threads, _i64=True)
+
+
+wrap_encode_i64 = wrap_encode_i64_threaded = _no_i64
 wrap_float64_to_int64 = wrap_int64_to_float64 = _no_i64
 
 
@@ -179,11 +184,9 @@ def decode_flac(compressed, starts, nbytes, stream_size, first_sample=-1, last_s
         if first_sample >= last_sample:
             raise RuntimeError("first_sample is larger than last_sample")
         n_decode = last_sample - first_sample
-    if is_int64:
-        raise NotImplementedError(_NOT_I64)
     output_shape = starts.shape + (n_decode,)
     n_stream = int(np.prod(starts.shape))
-    flat_output = wrap_decode_i32(
+    flat_output = (wrap_decode_i64 if is_int64 else wrap_decode_i32)(
         compressed, starts.reshape((-1,)), nbytes.reshape((-1,)), n_stream, int(stream_size), int(first_sample),
         int(last_sample), use_threads,
     )
@@ -276,9 +279,11 @@ def encode_flac_device(data, level=5, workspace=None, return_info=False):
     return out
 
 
-def decode_flac_device(compressed, starts, nbytes, stream_size, first_sample=-1, last_sample=-1, offsets=None, gains=None):
+def decode_flac_device(compressed, starts, nbytes, stream_size, first_sample=-1, last_sample=-1, offsets=None, gains=None,
+                       is_int64=False):
     """Decode device-resident streams into an int32 tensor (or float32 when offsets/gains are
-    given: the int->float restore of utils.c:350-368 is fused into the store)."""
+    given: the int->float restore of utils.c:350-368 is fused into the store).  is_int64:
+    two-channel streams -> int64 (or float64 with float64 offsets/gains, utils.c:329-348)."""
     torch = _torch()
     if compressed.dtype != torch.uint8:
         raise RuntimeError("Compressed data should be of type uint8")
@@ -305,6 +310,25 @@ def decode_flac_device(compressed, starts, nbytes, stream_size, first_sample=-1,
     shape = tuple(starts.shape) + (n_decode,)
     dev = compressed.device
     L = _lib.lib()
+    if is_int64:
+        with torch.cuda.device(dev):
+            if offsets is None:
+                out = torch.empty(shape, dtype=torch.int64, device=dev)
+                errcode = L.fa_decode_i64_device(
+                    _dp(compressed), compressed.numel(), _dp(starts), _dp(nbytes), n_stream, stream_size, first_sample,
+                    last_sample, _dp(out), None, None, None, _stream_ptr(),
+                )
+            else:
+                out = torch.empty(shape, dtype=torch.float64, device=dev)
+                offsets = offsets.to(device=dev, dtype=torch.float64).contiguous()
+                gains = gains.to(device=dev, dtype=torch.float64).contiguous()
+                errcode = L.fa_decode_i64_device(
+                    _dp(compressed), compressed.numel(), _dp(starts), _dp(nbytes), n_stream, stream_size, first_sample,
+                    last_sample, None, _dp(out), _dp(offsets), _dp(gains), _stream_ptr(),
+                )
+        if errcode != 0:
+            raise RuntimeError(f"Decoding failed, return code = {errcode}")
+        return out
     with torch.cuda.device(dev):
         if offsets is None:
             out = torch.empty(shape, dtype=torch.int32, device=dev)

@@ -58,6 +58,12 @@ int encode_i32_threaded(int32_t* const data, int64_t n_stream, int64_t stream_si
 int decode_i32(unsigned char* const bytes, int64_t* const starts, int64_t* const nbytes, int64_t n_stream,
                int64_t stream_size, int64_t first_sample, int64_t last_sample, int32_t* data, bool use_threads);
 
+/* replaces decode_i64, flacarray.h:261-271 (decompress.c:343-375): two-channel streams, int64
+ * sample = (channel 1 << 32) | (channel 0 as unsigned) (utils.c:96-123).  Reads streams with any
+ * stereo channel assignment (left/right, left/side, side/right, mid/side). */
+int decode_i64(unsigned char* const bytes, int64_t* const starts, int64_t* const nbytes, int64_t n_stream,
+               int64_t stream_size, int64_t first_sample, int64_t last_sample, int64_t* data, bool use_threads);
+
 /* replaces float32_to_int32, flacarray.h:275-283 (utils.c:160); quanta == NULL: per-stream
  * quanta from the data range */
 int float32_to_int32(float const* input, int64_t n_stream, int64_t stream_size, float const* quanta, int32_t* output,
@@ -96,6 +102,13 @@ int fa_decode_i32_device(const unsigned char* d_bytes, int64_t n_bytes, const in
                          int64_t last_sample, int32_t* d_out_i32, float* d_out_f32, const float* d_offsets,
                          const float* d_gains, void* stream);
 
+/* The same for two-channel (int64 / float64) streams; with d_out_f64 the int64 -> float64 restore
+ * (int64_to_float64, utils.c:329-348) is fused into the final pass. */
+int fa_decode_i64_device(const unsigned char* d_bytes, int64_t n_bytes, const int64_t* d_starts,
+                         const int64_t* d_nbytes, int64_t n_stream, int64_t stream_size, int64_t first_sample,
+                         int64_t last_sample, int64_t* d_out_i64, double* d_out_f64, const double* d_offsets,
+                         const double* d_gains, void* stream);
+
 /* Batched random access: slice i is samples [first[i], first[i]+count[i]) of stream
  * slice_stream[i]; its samples are written at element offset out_offset[i] of the output.
  * The four slice arrays are HOST arrays of length n_slices.  The reference needs one
@@ -105,6 +118,12 @@ int fa_decode_slices_i32_device(const unsigned char* d_bytes, int64_t n_bytes, c
                                 const int64_t* slice_stream, const int64_t* slice_first, const int64_t* slice_count,
                                 const int64_t* out_offset, int32_t* d_out_i32, float* d_out_f32,
                                 const float* d_offsets, const float* d_gains, void* stream);
+
+int fa_decode_slices_i64_device(const unsigned char* d_bytes, int64_t n_bytes, const int64_t* d_starts,
+                                const int64_t* d_nbytes, int64_t n_stream, int64_t stream_size, int64_t n_slices,
+                                const int64_t* slice_stream, const int64_t* slice_first, const int64_t* slice_count,
+                                const int64_t* out_offset, int64_t* d_out_i64, double* d_out_f64,
+                                const double* d_offsets, const double* d_gains, void* stream);
 
 /* float32 -> int32 quantisation on device; d_quanta may be NULL.  Returns FA_ERROR_NAN_INPUT
  * if any input is NaN (outputs are then unspecified). */

@@ -1,4 +1,6 @@
 """GPU parity: the HIP path against the CPU oracle on the same seeded inputs (bit-exact)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -349,3 +351,69 @@ def test_hdf5_write_read_array(fa):
     assert g3["stream_starts"].shape == (1,)
     assert fa.FlacArray.read_hdf5(g3).shape == (20000,)
     assert fa.FlacArray.read_hdf5(g3, no_flatten=True).shape == (1, 20000)
+
+
+# ---- two-channel (int64 / float64) arrays ----------------------------------------------------
+STEREO_GOLDEN = ["g8_stereo_lr", "g9_stereo_ls", "g10_stereo_sr", "g11_stereo_ms", "g12_stereo16", "g13_stereo_pred"]
+
+
+def _i64_cases():
+    rng = np.random.default_rng(64)
+    n = 3 * 4096 + 777
+    x = np.empty((6, n), dtype=np.int64)
+    x[0] = np.cumsum(rng.integers(-(2**20), 2**20, n)) + 2**40           # counter above 2^32: the low word wraps
+    x[1] = rng.integers(-(2**62), 2**62, n)                              # incompressible
+    x[2] = -(2**63)                                                      # constant
+    x[3] = (np.arange(n, dtype=np.int64) - 4500) * 1000003               # ramp
+    x[4] = np.rint(2.0**45 * np.sin(np.arange(n) / 50.0)).astype(np.int64) + rng.integers(-(2**30), 2**30, n)
+    x[5] = rng.integers(-5, 6, n) * 2**33                                # low word zero, wasted bits in the high word
+    x[1, :4] = [2**63 - 1, -(2**63), 2**32, -1]
+    return x
+
+
+@pytest.mark.parametrize("name", STEREO_GOLDEN)
+def test_decode_hand_assembled_stereo_streams(fa, name):
+    """Two-channel streams assembled field by field (tests/golden/make_golden.py): every stereo channel
+    assignment, 33-bit side channels (VERBATIM, FIXED and LPC), 16-bit stereo; no SEEKTABLE."""
+    import torch
+
+    v = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "flac_vectors.npz"))
+    s, st, n = v[name + "_samples"], v[name + "_stream"], int(v[name + "_size"])
+    dev = torch.device("cuda", 0)
+    blob = torch.from_numpy(np.concatenate([st, st])).to(dev)
+    starts = torch.tensor([st.size, 0], dtype=torch.int64, device=dev)
+    nbytes = torch.tensor([st.size, st.size], dtype=torch.int64, device=dev)
+    y = fa.decode_flac_device(blob, starts, nbytes, n, is_int64=True).cpu().numpy()
+    assert np.array_equal(y[0], s) and np.array_equal(y[1], s)
+    lo, hi = n // 3, n - 1
+    y = fa.decode_flac_device(blob, starts, nbytes, n, lo, hi, is_int64=True).cpu().numpy()
+    assert np.array_equal(y[0], s[lo:hi])
+    with pytest.raises(RuntimeError):  # not an int32 stream
+        fa.decode_flac_device(blob, starts, nbytes, n)
+
+
+@pytest.mark.parametrize("level", [0, 5, 8])
+def test_decode_i64_oracle_streams(fa, oracle, level):
+    import torch
+
+    from tests.conftest import strip_seektable
+
+    x = _i64_cases()
+    n = x.shape[1]
+    blob, st, nb = oracle.encode_i64(x, level)
+    dev = torch.device("cuda", 0)
+    tb, ts, tn = (torch.from_numpy(a).to(dev) for a in (blob, st, nb))
+    assert np.array_equal(fa.decode_flac_device(tb, ts, tn, n, is_int64=True).cpu().numpy(), x)
+    assert np.array_equal(fa.decode_flac_device(tb, ts, tn, n, 4000, 9001, is_int64=True).cpu().numpy(), x[:, 4000:9001])
+    # host ABI (decode_i64) through the reference-named wrapper
+    assert np.array_equal(fa.decode_flac(blob, st, nb, n, is_int64=True), x)
+    assert np.array_equal(fa.decode_flac(blob, st, nb, n, 10, 20, is_int64=True), x[:, 10:20])
+    # without a seek table: sync-code scan on two-channel headers
+    b2, s2, n2 = strip_seektable(blob, st, nb)
+    t2 = [torch.from_numpy(a).to(dev) for a in (b2, s2, n2)]
+    assert np.array_equal(fa.decode_flac_device(*t2, n, is_int64=True).cpu().numpy(), x)
+    # float64 restore fused into the final pass
+    off = np.linspace(-3, 3, x.shape[0])
+    gain = np.full(x.shape[0], 2.0**20)
+    yf = fa.decode_flac_device(tb, ts, tn, n, offsets=torch.from_numpy(off), gains=torch.from_numpy(gain), is_int64=True).cpu().numpy()
+    assert np.array_equal(yf, oracle.int64_to_float64(x, off, gain))
