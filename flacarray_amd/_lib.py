@@ -15,6 +15,8 @@ SYMBOLS = [
     "encode_i32_threaded",
     "decode_i32",
     "decode_i64",
+    "encode_i64",
+    "encode_i64_threaded",
     "float32_to_int32",
     "int32_to_float32",
     "fa_encode_workspace_bytes",
@@ -23,6 +25,9 @@ SYMBOLS = [
     "fa_decode_i32_device",
     "fa_decode_slices_i32_device",
     "fa_decode_i64_device",
+    "fa_encode_workspace_bytes_i64",
+    "fa_encode_i64_device_begin",
+    "fa_encode_i64_device_finish",
     "fa_decode_slices_i64_device",
     "fa_float32_to_int32_device",
     "fa_int32_to_float32_device",
@@ -67,8 +72,6 @@ def lib():
     L.encode_i32_threaded.restype = cint
     L.decode_i32.argtypes = [vp, vp, vp, i64, i64, i64, i64, vp, ctypes.c_bool]
     L.decode_i32.restype = cint
-    L.decode_i64.argtypes = L.decode_i32.argtypes
-    L.decode_i64.restype = cint
     L.float32_to_int32.argtypes = [vp, i64, i64, vp, vp, vp, vp]
     L.float32_to_int32.restype = cint
     L.int32_to_float32.argtypes = [vp, i64, i64, vp, vp, vp]
@@ -83,10 +86,6 @@ def lib():
     L.fa_decode_i32_device.restype = cint
     L.fa_decode_slices_i32_device.argtypes = [vp, i64, vp, vp, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.fa_decode_slices_i32_device.restype = cint
-    L.fa_decode_i64_device.argtypes = L.fa_decode_i32_device.argtypes
-    L.fa_decode_i64_device.restype = cint
-    L.fa_decode_slices_i64_device.argtypes = L.fa_decode_slices_i32_device.argtypes
-    L.fa_decode_slices_i64_device.restype = cint
     L.fa_float32_to_int32_device.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp]
     L.fa_float32_to_int32_device.restype = cint
     L.fa_int32_to_float32_device.argtypes = [vp, i64, i64, vp, vp, vp, vp]
@@ -101,8 +100,31 @@ def lib():
     L.fa_device_count.restype = cint
     L.fa_version.argtypes = []
     L.fa_version.restype = ctypes.c_char_p
+    # two-channel (int64 / float64) entry points; an older diagnostic build selected through
+    # FLACARRAY_HIP_LIB for an A/B run may lack them
+    if hasattr(L, "decode_i64") or not os.environ.get("FLACARRAY_HIP_LIB"):
+        _declare_i64(L)
     _lib = L
     return L
+
+
+def _declare_i64(L):
+    cint = ctypes.c_int
+    L.decode_i64.argtypes = L.decode_i32.argtypes
+    L.decode_i64.restype = cint
+    for name in ("encode_i64", "encode_i64_threaded"):
+        getattr(L, name).argtypes = L.encode_i32.argtypes
+        getattr(L, name).restype = cint
+    L.fa_encode_workspace_bytes_i64.argtypes = L.fa_encode_workspace_bytes.argtypes
+    L.fa_encode_workspace_bytes_i64.restype = ctypes.c_int64
+    L.fa_encode_i64_device_begin.argtypes = L.fa_encode_i32_device_begin.argtypes
+    L.fa_encode_i64_device_begin.restype = cint
+    L.fa_encode_i64_device_finish.argtypes = L.fa_encode_i32_device_finish.argtypes
+    L.fa_encode_i64_device_finish.restype = cint
+    L.fa_decode_i64_device.argtypes = L.fa_decode_i32_device.argtypes
+    L.fa_decode_i64_device.restype = cint
+    L.fa_decode_slices_i64_device.argtypes = L.fa_decode_slices_i32_device.argtypes
+    L.fa_decode_slices_i64_device.restype = cint
 
 
 def libc_free(addr):

@@ -43,7 +43,8 @@ struct EncodeArgs {
     int32_t precision;
     const float* win;       // [B]
     const float* win_tail;  // [tail_bs]
-    uint8_t* slots;         // [n_stream*nframes][kSlotBytes]
+    uint8_t* slots;         // [n_stream*nframes][slot_stride]
+    int64_t slot_stride;    // kSlotBytes per channel
     uint32_t* frame_bytes;  // [n_stream*nframes]
     FrameInfo* info;        // [n_stream*nframes] or null
     unsigned long long* stamps;  // diagnostic build (-DFA_STAMPS): per-phase cycle sums
@@ -375,9 +376,10 @@ __device__ __forceinline__ uint64_t rice_search_wave(uint64_t S, int bs, int pre
 
 // (Re)load the frame's samples from global memory into the LDS chunk image, applying the
 // wasted-bits shift.  Returns this lane's OR of valid samples and whether all equal `first`.
+// stride / choff select one channel of a sample-interleaved two-channel frame.
 __device__ __forceinline__ void load_frame(const int32_t* __restrict__ src, int bs, int wasted, int32_t* smp, int lane,
-                                           uint32_t* orv_out, bool* alleq_out, int32_t first) {
-    const bool aligned = ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+                                           uint32_t* orv_out, bool* alleq_out, int32_t first, int stride = 1, int choff = 0) {
+    const bool aligned = (stride == 1) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
     const int nrows = (bs + kRow - 1) / kRow;
     uint32_t orv = 0;
     bool alleq = true;
@@ -387,10 +389,10 @@ __device__ __forceinline__ void load_frame(const int32_t* __restrict__ src, int 
         if (aligned && base + 3 < bs) {
             v = *reinterpret_cast<const int4*>(src + base);
         } else {
-            if (base + 0 < bs) v.x = src[base + 0];
-            if (base + 1 < bs) v.y = src[base + 1];
-            if (base + 2 < bs) v.z = src[base + 2];
-            if (base + 3 < bs) v.w = src[base + 3];
+            if (base + 0 < bs) v.x = src[(size_t)(base + 0) * stride + choff];
+            if (base + 1 < bs) v.y = src[(size_t)(base + 1) * stride + choff];
+            if (base + 2 < bs) v.z = src[(size_t)(base + 2) * stride + choff];
+            if (base + 3 < bs) v.w = src[(size_t)(base + 3) * stride + choff];
         }
         if (base + 0 < bs) { orv |= (uint32_t)v.x; alleq = alleq && (v.x == first); }
         if (base + 1 < bs) { orv |= (uint32_t)v.y; alleq = alleq && (v.y == first); }
@@ -406,32 +408,67 @@ __device__ __forceinline__ void load_frame(const int32_t* __restrict__ src, int 
 // ------------------------------------------------------------------------------------------
 // K3: one wavefront encodes one frame
 // ------------------------------------------------------------------------------------------
-template <int MLO>  // level's maximum LPC order: 0 (fixed predictors only), 6, 8 or 12
+// MLO: level's maximum LPC order: 0 (fixed predictors only), 6, 8 or 12.
+// NCH: channels per frame.  2 = the reference's int64 arrays (compress.c:482-511): sample-interleaved
+// low / high words, coded as two independent subframes (channel assignment 0b0001) one after the
+// other into the same bit ring.
+template <int MLO, int NCH = 1>
 __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
+    constexpr int kScrWords = (NCH == 2) ? 256 : 0;  // analysis scratch: the ring holds live bits while channel 1 is analysed
 #ifdef FA_LDS_PAD
-    __shared__ __attribute__((aligned(16))) int32_t lds[kLdsWords + FA_LDS_PAD];  // occupancy experiment
+    __shared__ __attribute__((aligned(16))) int32_t lds[kLdsWords + kScrWords + FA_LDS_PAD];  // occupancy experiment
 #else
-    __shared__ __attribute__((aligned(16))) int32_t lds[kLdsWords];
+    __shared__ __attribute__((aligned(16))) int32_t lds[kLdsWords + kScrWords];
 #endif
     int32_t* smp = lds;
     uint32_t* ring = reinterpret_cast<uint32_t*>(lds + kSmpWords);
     uint64_t* psum = reinterpret_cast<uint64_t*>(lds + kSmpWords + kRingWords + 2);
     uint8_t* kpar = reinterpret_cast<uint8_t*>(lds + kSmpWords + kRingWords + 2 + 128);
+    uint32_t* scr = (NCH == 2) ? reinterpret_cast<uint32_t*>(lds + kLdsWords) : ring;
+    (void)psum;
 
     const int lane = threadIdx.x;
     const int64_t g = blockIdx.x;
     const int64_t s = g / a.nframes;
     const int64_t f = g - s * a.nframes;
     const int bs = (f == a.nframes - 1) ? a.tail_bs : a.B;
-    const int32_t* src = a.data + s * a.stream_size + f * (int64_t)a.B;
+    const int32_t* src = a.data + (s * a.stream_size + f * (int64_t)a.B) * NCH;
     const float* win = (bs == a.B) ? a.win : a.win_tail;
     const int nrows = (bs + kRow - 1) / kRow;
     const bool active = (kChunk * lane < bs);
 
     FA_STAMP_INIT;
+    // frame-level writer state: bit position, flushed 256-byte blocks, the zeroed ring
+    uint8_t* slot = a.slots + (size_t)g * (size_t)a.slot_stride;
+    uint32_t total_bytes = 0;
+    uint32_t pos = 0;
+    uint32_t blocks_flushed = 0;
+    if constexpr (NCH == 2) {  // (one-channel frames zero the ring when they start to emit: it is analysis scratch before)
+        for (int i = lane; i < kRingWords; i += 64) ring[i] = 0;
+        if (lane == 0) ring[kRingWords] = 0;
+    }
+    // frame header bit count (needed for the exact subframe size): 8*(4 + utf8 + bs bytes + 1)
+    uint32_t fh_bits;
+    {
+        const uint64_t fn = (uint64_t)f;
+        int nb = (fn < 0x80) ? 1 : (fn < 0x800) ? 2 : (fn < 0x10000) ? 3 : (fn < 0x200000) ? 4 : (fn < 0x4000000) ? 5 : 6;
+        const int bsc = blocksize_code(bs);
+        fh_bits = 8u * (uint32_t)(4 + nb + (bsc == 6 ? 1 : bsc == 7 ? 2 : 0) + 1);
+    }
+
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+    // writer state at the start of this subframe: a VERBATIM retry rewinds to it.  Everything not yet
+    // flushed lies in block bf0 (one word per lane) and, when bf0 opens a ring cycle, the mirror word.
+    const uint32_t pos0 = pos, bf0 = blocks_flushed;
+    uint32_t save_w = 0, save_m = 0;
+    if (NCH == 2 && ch > 0) {
+        save_w = ring[(bf0 * 64 + lane) & kRingMask];
+        save_m = ring[kRingWords];
+    }
     // ---- P0: stage samples, wasted bits, constant test ---------------------------------
     for (int i = lane; i < kChunkStride; i += 64) smp[i] = 0;  // chunk -1 = zero history
-    const int32_t first = src[0];
+    const int32_t first = src[ch];
     uint32_t orv = 0;
     bool narrow, is_const;
     const bool full = (bs == kMaxBlock) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
@@ -439,18 +476,42 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
         // all 16 row loads in flight at once (64 KB per CU outstanding at 8 waves); the running
         // minimum / maximum (v_min3 / v_max3: half an instruction per sample each) answer both
         // "constant?" and "narrow?"
-        int4 v[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<const int4*>(src + kRow * j + 4 * lane);
         int mn = first, mx = first;
+        if constexpr (NCH == 1) {
+            int4 v[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            orv |= (uint32_t)(v[j].x | v[j].y | v[j].z | v[j].w);
-            mn = min(min(mn, v[j].x), v[j].y);
-            mn = min(min(mn, v[j].z), v[j].w);
-            mx = max(max(mx, v[j].x), v[j].y);
-            mx = max(max(mx, v[j].z), v[j].w);
-            *reinterpret_cast<int4*>(&smp[smp_idx(kRow * j + 4 * lane)]) = v[j];
+            for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<const int4*>(src + kRow * j + 4 * lane);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                orv |= (uint32_t)(v[j].x | v[j].y | v[j].z | v[j].w);
+                mn = min(min(mn, v[j].x), v[j].y);
+                mn = min(min(mn, v[j].z), v[j].w);
+                mx = max(max(mx, v[j].x), v[j].y);
+                mx = max(max(mx, v[j].z), v[j].w);
+                *reinterpret_cast<int4*>(&smp[smp_idx(kRow * j + 4 * lane)]) = v[j];
+            }
+        } else {
+            // interleaved pairs: 8 consecutive words hold this lane's 4 samples of both channels
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {
+                int4 va[8], vb[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int32_t* q = src + 2 * (kRow * (8 * half + j) + 4 * lane);
+                    va[j] = *reinterpret_cast<const int4*>(q);
+                    vb[j] = *reinterpret_cast<const int4*>(q + 4);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int4 v = (ch == 0) ? make_int4(va[j].x, va[j].z, vb[j].x, vb[j].z) : make_int4(va[j].y, va[j].w, vb[j].y, vb[j].w);
+                    orv |= (uint32_t)(v.x | v.y | v.z | v.w);
+                    mn = min(min(mn, v.x), v.y);
+                    mn = min(min(mn, v.z), v.w);
+                    mx = max(max(mx, v.x), v.y);
+                    mx = max(max(mx, v.z), v.w);
+                    *reinterpret_cast<int4*>(&smp[smp_idx(kRow * (8 * half + j) + 4 * lane)]) = v;
+                }
+            }
         }
         mn = wave_min_i32(mn);
         mx = wave_max_i32(mx);
@@ -458,7 +519,7 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
         narrow = (mn >= -(1 << 24)) && (mx < (1 << 24));  // every |x| <= 2^24: fixed-predictor errors fit 32-bit ints
     } else {
         bool alleq = true;
-        load_frame(src, bs, 0, smp, lane, &orv, &alleq, first);
+        load_frame(src, bs, 0, smp, lane, &orv, &alleq, first, NCH, ch);
         is_const = __all(alleq);
         narrow = false;  // generic path: no narrow shortcut
     }
@@ -688,11 +749,10 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
 
                 FA_STAMP(5);
                 if (autoc[0] != 0.0) {
-                    // scratch in the (still unused) ring area
-                    float* coef = reinterpret_cast<float*>(ring);               // MLO*MLO floats
-                    double* err = reinterpret_cast<double*>(ring + 160);        // MLO doubles
-                    int32_t* qc = reinterpret_cast<int32_t*>(ring + 200);       // MLO ints
-                    int* meta = reinterpret_cast<int*>(ring + 220);             // ok, lo, prec, shift
+                    // scratch: the (still unused) ring area for one-channel frames, its own area otherwise
+                    float* coef = reinterpret_cast<float*>(scr);               // MLO*MLO floats
+                    double* err = reinterpret_cast<double*>(scr + 160);        // MLO doubles
+                    int* meta = reinterpret_cast<int*>(scr + 220);             // usable order
                     if (lane == 0) meta[0] = levinson<MLO>(autoc, mlo, coef, err);
                     lds_fence();
                     const int usable = meta[0];
@@ -824,8 +884,6 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
 
     FA_STAMP(8);
     // ---- emit (with one possible VERBATIM retry) ---------------------------------------
-    uint8_t* slot = a.slots + (size_t)g * kSlotBytes;
-    uint32_t total_bytes = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         // make the LDS image hold what this subframe type needs
         if (type == 3) {
@@ -833,7 +891,7 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
         } else {
             if (lds_is_residual) {
                 uint32_t o2; bool e2;
-                load_frame(src, bs, wasted, smp, lane, &o2, &e2, first);
+                load_frame(src, bs, wasted, smp, lane, &o2, &e2, first, NCH, ch);
                 lds_is_residual = false;
                 lds_fence();
             }
@@ -867,11 +925,17 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                 lds_is_residual = true;
             }
         }
-        // Rice parameter table and ring reset
+        // Rice parameter table; ring as it was when this subframe began (all zero for channel 0)
         kpar[lane] = (uint8_t)kbest;
         for (int i = lane; i < kRingWords; i += 64) ring[i] = 0;
-        if (lane == 0) ring[kRingWords] = 0;
+        if (lane == 0) ring[kRingWords] = save_m;
         lds_fence();
+        if (NCH == 2 && ch > 0) {
+            ring[(bf0 * 64 + lane) & kRingMask] = save_w;
+            lds_fence();
+        }
+        pos = pos0;
+        blocks_flushed = bf0;
 
         bool rice2 = false;
         if (type >= 2) rice2 = __any((lane < (1 << porder)) && (kbest >= 15));
@@ -889,7 +953,6 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
             atomicOr(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ring) + a0), (uint32_t)(X >> 32));
             atomicOr(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ring) + a0 + 4), (uint32_t)X);  // may be the mirror word
         };
-        uint32_t pos = 0;
         {
             // wave-uniform header bytes and their CRC-8
             const int bsc = blocksize_code(bs);
@@ -903,7 +966,8 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
             }
             uint8_t c8 = crc8_byte(crc8_byte(0, 0xFF), 0xF8);
             c8 = crc8_byte(c8, (uint8_t)b2);
-            c8 = crc8_byte(c8, 0x0E);  // mono, 32 bits per sample, reserved 0
+            constexpr uint32_t b3 = ((uint32_t)(NCH - 1) << 4) | 0x0Eu;  // mono or two independent channels, 32 bits per sample, reserved 0
+            c8 = crc8_byte(c8, (uint8_t)b3);
             for (int i = nbu - 1; i >= 0; --i) c8 = crc8_byte(c8, (uint8_t)(ub >> (8 * i)));
             if (bsc == 6) c8 = crc8_byte(c8, (uint8_t)(bs - 1));
             else if (bsc == 7) { c8 = crc8_byte(c8, (uint8_t)((bs - 1) >> 8)); c8 = crc8_byte(c8, (uint8_t)(bs - 1)); }
@@ -914,11 +978,16 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
             constexpr int kL_warm = 6, kL_lpc = kL_warm + kWarmLanes, kL_coef = kL_lpc + 1, kL_rice = kL_coef + ((MLO > 0) ? MLO : 1);
             static_assert(kL_rice < 64, "preamble fields must fit the wave");
             uint32_t fv = 0, fnb = 0;
-            if (lane == 0) { fv = 0xFFF80000u | (b2 << 8) | 0x0Eu; fnb = 32; }
-            else if (lane == 1) { const int n1 = nbu > 4 ? 4 : nbu; fv = (uint32_t)(ub >> (8 * (nbu - n1))); fnb = 8u * (uint32_t)n1; }
-            else if (lane == 2) { if (nbu > 4) { fnb = 8u * (uint32_t)(nbu - 4); fv = (uint32_t)ub & ((1u << fnb) - 1u); } }
-            else if (lane == 3) { if (bsc == 6) { fv = (uint32_t)(bs - 1); fnb = 8; } else if (bsc == 7) { fv = (uint32_t)(bs - 1); fnb = 16; } }
-            else if (lane == 4) { fv = ((uint32_t)c8 << 8) | (uint32_t)((tc << 1) | (wasted ? 1 : 0)); fnb = 16; }
+            const bool fh = (ch == 0);  // the frame header precedes the first subframe only
+            if (lane == 0) { if (fh) { fv = 0xFFF80000u | (b2 << 8) | b3; fnb = 32; } }
+            else if (lane == 1) { if (fh) { const int n1 = nbu > 4 ? 4 : nbu; fv = (uint32_t)(ub >> (8 * (nbu - n1))); fnb = 8u * (uint32_t)n1; } }
+            else if (lane == 2) { if (fh && nbu > 4) { fnb = 8u * (uint32_t)(nbu - 4); fv = (uint32_t)ub & ((1u << fnb) - 1u); } }
+            else if (lane == 3) { if (fh) { if (bsc == 6) { fv = (uint32_t)(bs - 1); fnb = 8; } else if (bsc == 7) { fv = (uint32_t)(bs - 1); fnb = 16; } } }
+            else if (lane == 4) {
+                fv = (uint32_t)((tc << 1) | (wasted ? 1 : 0));
+                fnb = 8;
+                if (fh) { fv |= (uint32_t)c8 << 8; fnb = 16; }
+            }
             else if (lane == 5) { if (wasted) { fv = 1; fnb = (uint32_t)wasted; } }  // unary: wasted-1 zeros, then 1
             else if (lane < kL_lpc) { if (lane - kL_warm < nwarm) { fv = (uint32_t)smp[smp_idx(lane - kL_warm)] & smask; fnb = (uint32_t)bps; } }
             else if (lane == kL_lpc) { if (type == 3) { fv = ((uint32_t)(precision - 1) << 5) | (uint32_t)shift; fnb = 9; } }
@@ -935,26 +1004,16 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
             }
             else if (lane == kL_rice) { if (type >= 2) { fv = ((rice2 ? 1u : 0u) << 4) | (uint32_t)porder; fnb = 6; } }
             const uint32_t incl = wave_incl_scan_u32(fnb);
-            if (fnb) put_bits(incl - fnb, fv, fnb);
-            pos = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (fnb) put_bits(pos0 + incl - fnb, fv, fnb);
+            pos = pos0 + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
         lds_fence();
-
-        // frame header bit count (needed for the exact subframe size): 8*(4 + utf8 + bs bytes + 1)
-        uint32_t fh_bits;
-        {
-            const uint64_t fn = (uint64_t)f;
-            int nb = (fn < 0x80) ? 1 : (fn < 0x800) ? 2 : (fn < 0x10000) ? 3 : (fn < 0x200000) ? 4 : (fn < 0x4000000) ? 5 : 6;
-            const int bsc = blocksize_code(bs);
-            fh_bits = 8u * (uint32_t)(4 + nb + (bsc == 6 ? 1 : bsc == 7 ? 2 : 0) + 1);
-        }
 
         FA_STAMP(10);
         // ---- rows: 4 consecutive samples per lane, scan of code lengths, OR into the ring ----
         // Branch-free per item: an item that does not exist (warm-up sample, past the end of the
         // frame) has length 0 and ORs zeros.
         bool overflow = false;
-        uint32_t blocks_flushed = 0;
         auto flush_blocks = [&]() __attribute__((always_inline)) {
             // no fence: DS operations of one wavefront are processed in issue order, so these
             // reads see every earlier ds_or of this wave
@@ -1062,7 +1121,7 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
         }
         FA_STAMP(11);
         if (!overflow && type >= 2) {
-            const uint64_t exact = (uint64_t)pos - fh_bits;
+            const uint64_t exact = (uint64_t)pos - (pos0 + (ch == 0 ? fh_bits : 0u));
             if (exact > verbatim_bits) overflow = true;
         }
         if (overflow) {
@@ -1071,10 +1130,27 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
             porder = 0;
             continue;  // second attempt writes the VERBATIM subframe
         }
-        // ---- tail: byte align, 16 zero bits for the CRC-16 (filled in by K5), final flush ----
-        pos = (pos + 7u) & ~7u;
-        pos += 16;
-        total_bytes = pos >> 3;
+        break;
+    }
+    if (lane == 0 && a.info) {
+        FrameInfo fi;
+        fi.type = type;
+        fi.order = (type >= 2) ? order : 0;
+        fi.porder = (type >= 2) ? porder : 0;
+        fi.wasted = wasted;
+        fi.shift = (type == 3) ? shift : 0;
+        fi.precision = (type == 3) ? precision : 0;
+        fi.nbytes = 0;  // filled in below, once the frame is complete
+        fi.blocksize = bs;
+        a.info[g * NCH + ch] = fi;
+    }
+    }  // channel loop
+
+    // ---- tail: byte align, 16 zero bits for the CRC-16 (filled in by K5), final flush ----
+    pos = (pos + 7u) & ~7u;
+    pos += 16;
+    total_bytes = pos >> 3;
+    {
         const uint32_t nwords = (total_bytes + 3) >> 2;
         for (uint32_t w0 = blocks_flushed * 64; w0 < nwords; w0 += 64) {
             const uint32_t wl = w0 + lane;
@@ -1084,24 +1160,13 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                 reinterpret_cast<uint32_t*>(slot)[wl] = __builtin_bswap32(wv);
             }
         }
-        break;
     }
     FA_STAMP(12);
     FA_STAMP_FLUSH;
     if (lane == 0) {
         a.frame_bytes[g] = total_bytes;
-        if (a.info) {
-            FrameInfo fi;
-            fi.type = type;
-            fi.order = (type >= 2) ? order : 0;
-            fi.porder = (type >= 2) ? porder : 0;
-            fi.wasted = wasted;
-            fi.shift = (type == 3) ? shift : 0;
-            fi.precision = (type == 3) ? precision : 0;
-            fi.nbytes = (int32_t)total_bytes;
-            fi.blocksize = bs;
-            a.info[g] = fi;
-        }
+        if (a.info)
+            for (int c = 0; c < NCH; ++c) a.info[g * NCH + c].nbytes = (int32_t)total_bytes;
     }
 }
 
@@ -1170,7 +1235,7 @@ __global__ __launch_bounds__(1024) void starts_scan_kernel(const int64_t* __rest
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void write_headers_kernel(uint8_t* __restrict__ out, const int64_t* __restrict__ starts,
                                                             const int64_t* __restrict__ frame_off, int64_t nframes,
-                                                            int64_t stream_size, int32_t B, int32_t tail_bs) {
+                                                            int64_t stream_size, int32_t B, int32_t tail_bs, int32_t nch) {
     const int64_t s = blockIdx.x;
     uint8_t* h = out + starts[s];
     const int tid = threadIdx.x;
@@ -1181,7 +1246,7 @@ __global__ __launch_bounds__(256) void write_headers_kernel(uint8_t* __restrict_
         si[0] = (uint8_t)(B >> 8); si[1] = (uint8_t)B; si[2] = (uint8_t)(B >> 8); si[3] = (uint8_t)B;
         for (int i = 4; i < 10; ++i) si[i] = 0;
         const uint64_t ts = ((uint64_t)stream_size < (1ULL << 36)) ? (uint64_t)stream_size : 0;
-        const uint64_t packed = ((uint64_t)44100 << 44) | ((uint64_t)31 << 36) | ts;
+        const uint64_t packed = ((uint64_t)44100 << 44) | ((uint64_t)(nch - 1) << 41) | ((uint64_t)31 << 36) | ts;
         for (int i = 0; i < 8; ++i) si[10 + i] = (uint8_t)(packed >> (56 - 8 * i));
         for (int i = 18; i < 34; ++i) si[i] = 0;
         uint8_t* t = h + 42;
@@ -1223,7 +1288,7 @@ __global__ __launch_bounds__(256) void compact_frames_kernel(const uint8_t* __re
                                                              const int64_t* __restrict__ frame_off,
                                                              const int64_t* __restrict__ starts, int64_t nframes,
                                                              int64_t total_frames, const uint16_t* __restrict__ crc_tab,
-                                                             uint8_t* __restrict__ out) {
+                                                             uint8_t* __restrict__ out, int64_t slot_stride) {
     __shared__ uint16_t tab[kCrcTabWords];
     for (int i = threadIdx.x; i < kCrcTabWords; i += 256) tab[i] = crc_tab[i];
     __syncthreads();
@@ -1233,7 +1298,7 @@ __global__ __launch_bounds__(256) void compact_frames_kernel(const uint8_t* __re
     for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < total_frames; g += (int64_t)gridDim.x * 4) {
         const int64_t s = g / nframes;
         const uint32_t n = frame_bytes[g];
-        const uint32_t* srcw = reinterpret_cast<const uint32_t*>(slots + (size_t)g * kSlotBytes);
+        const uint32_t* srcw = reinterpret_cast<const uint32_t*>(slots + (size_t)g * (size_t)slot_stride);
         const uint8_t* srcb = reinterpret_cast<const uint8_t*>(srcw);
         uint8_t* dst = out + starts[s] + hb + frame_off[g];
         const uint32_t L = n - 2;  // bytes covered by the CRC

@@ -159,9 +159,10 @@ struct EncodePlan {
     int64_t nf, F;
     int tail_bs;
     size_t off_slots, off_fbytes, off_foff, off_snb, off_total, total;
+    int64_t slot_stride;
 };
 
-int make_plan(int64_t n_stream, int64_t stream_size, uint32_t level, EncodePlan* pl) {
+int make_plan(int64_t n_stream, int64_t stream_size, uint32_t level, EncodePlan* pl, int nch = 1) {
     if (level > 8) return FA_ERROR_INVALID_LEVEL;
     if (n_stream <= 0) return FA_ERROR_ZERO_NSTREAM;
     if (stream_size <= 0) return FA_ERROR_ZERO_STREAMSIZE;
@@ -173,7 +174,8 @@ int make_plan(int64_t n_stream, int64_t stream_size, uint32_t level, EncodePlan*
     if (pl->nf > 0x7fffffffLL / n_stream) return FA_ERROR_ENCODE_PROCESS;  // grid limit; host API chunks
     pl->F = n_stream * pl->nf;
     size_t o = 0;
-    pl->off_slots = o;  o = align_up(o + (size_t)pl->F * kSlotBytes, 256);
+    pl->slot_stride = (int64_t)kSlotBytes * nch;
+    pl->off_slots = o;  o = align_up(o + (size_t)pl->F * (size_t)pl->slot_stride, 256);
     pl->off_fbytes = o; o = align_up(o + (size_t)pl->F * 4, 256);
     pl->off_foff = o;   o = align_up(o + (size_t)pl->F * 8, 256);
     pl->off_snb = o;    o = align_up(o + (size_t)n_stream * 8, 256);
@@ -182,9 +184,9 @@ int make_plan(int64_t n_stream, int64_t stream_size, uint32_t level, EncodePlan*
     return FA_ERROR_NONE;
 }
 
-template <int MLO>
+template <int MLO, int NCH>
 void launch_encode(const EncodeArgs& a, int64_t F, hipStream_t st) {
-    hipLaunchKernelGGL(encode_frames_kernel<MLO>, dim3((unsigned)F), dim3(64), 0, st, a);
+    hipLaunchKernelGGL((encode_frames_kernel<MLO, NCH>), dim3((unsigned)F), dim3(64), 0, st, a);
 }
 
 int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int64_t* d_starts, const int64_t* d_nbytes,
@@ -413,11 +415,17 @@ int64_t fa_encode_workspace_bytes(int64_t n_stream, int64_t stream_size, uint32_
     return (int64_t)pl.total;
 }
 
-int fa_encode_i32_device_begin(const int32_t* d_data, int64_t n_stream, int64_t stream_size, uint32_t level,
+int64_t fa_encode_workspace_bytes_i64(int64_t n_stream, int64_t stream_size, uint32_t level) {
+    EncodePlan pl;
+    if (make_plan(n_stream, stream_size, level, &pl, 2) != FA_ERROR_NONE) return -1;
+    return (int64_t)pl.total;
+}
+
+static int encode_device_begin(const int32_t* d_data, int nch, int64_t n_stream, int64_t stream_size, uint32_t level,
                                void* d_workspace, int64_t workspace_bytes, int64_t* d_starts, int64_t* d_nbytes,
                                int64_t* h_total_bytes, int32_t* d_info, void* stream) {
     EncodePlan pl;
-    int rc = make_plan(n_stream, stream_size, level, &pl);
+    int rc = make_plan(n_stream, stream_size, level, &pl, nch);
     if (rc) return rc;
     if (!d_workspace || workspace_bytes < (int64_t)pl.total) return FA_ERROR_ALLOC;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -431,6 +439,7 @@ int fa_encode_i32_device_begin(const int32_t* d_data, int64_t n_stream, int64_t 
     rc = get_window(a.tail_bs, &a.win_tail);
     if (rc) return rc;
     a.slots = reinterpret_cast<uint8_t*>(ws + pl.off_slots);
+    a.slot_stride = pl.slot_stride;
     a.frame_bytes = reinterpret_cast<uint32_t*>(ws + pl.off_fbytes);
     a.info = reinterpret_cast<FrameInfo*>(d_info);
     a.stamps = nullptr;
@@ -445,11 +454,20 @@ int fa_encode_i32_device_begin(const int32_t* d_data, int64_t n_stream, int64_t 
     }
 #endif
     prof_begin(0, st);
-    switch (a.max_lpc_order) {
-        case 0: launch_encode<0>(a, pl.F, st); break;
-        case 6: launch_encode<6>(a, pl.F, st); break;
-        case 8: launch_encode<8>(a, pl.F, st); break;
-        default: launch_encode<12>(a, pl.F, st); break;
+    if (nch == 1) {
+        switch (a.max_lpc_order) {
+            case 0: launch_encode<0, 1>(a, pl.F, st); break;
+            case 6: launch_encode<6, 1>(a, pl.F, st); break;
+            case 8: launch_encode<8, 1>(a, pl.F, st); break;
+            default: launch_encode<12, 1>(a, pl.F, st); break;
+        }
+    } else {
+        switch (a.max_lpc_order) {
+            case 0: launch_encode<0, 2>(a, pl.F, st); break;
+            case 6: launch_encode<6, 2>(a, pl.F, st); break;
+            case 8: launch_encode<8, 2>(a, pl.F, st); break;
+            default: launch_encode<12, 2>(a, pl.F, st); break;
+        }
     }
     prof_end(0, st);
     int64_t* d_foff = reinterpret_cast<int64_t*>(ws + pl.off_foff);
@@ -464,10 +482,24 @@ int fa_encode_i32_device_begin(const int32_t* d_data, int64_t n_stream, int64_t 
     return FA_ERROR_NONE;
 }
 
-int fa_encode_i32_device_finish(int64_t n_stream, int64_t stream_size, uint32_t level, void* d_workspace,
+int fa_encode_i32_device_begin(const int32_t* d_data, int64_t n_stream, int64_t stream_size, uint32_t level,
+                               void* d_workspace, int64_t workspace_bytes, int64_t* d_starts, int64_t* d_nbytes,
+                               int64_t* h_total_bytes, int32_t* d_info, void* stream) {
+    return encode_device_begin(d_data, 1, n_stream, stream_size, level, d_workspace, workspace_bytes, d_starts, d_nbytes,
+                               h_total_bytes, d_info, stream);
+}
+
+int fa_encode_i64_device_begin(const int64_t* d_data, int64_t n_stream, int64_t stream_size, uint32_t level,
+                               void* d_workspace, int64_t workspace_bytes, int64_t* d_starts, int64_t* d_nbytes,
+                               int64_t* h_total_bytes, int32_t* d_info, void* stream) {
+    return encode_device_begin(reinterpret_cast<const int32_t*>(d_data), 2, n_stream, stream_size, level, d_workspace,
+                               workspace_bytes, d_starts, d_nbytes, h_total_bytes, d_info, stream);
+}
+
+static int encode_device_finish(int nch, int64_t n_stream, int64_t stream_size, uint32_t level, void* d_workspace,
                                 const int64_t* d_starts, unsigned char* d_bytes, void* stream) {
     EncodePlan pl;
-    int rc = make_plan(n_stream, stream_size, level, &pl);
+    int rc = make_plan(n_stream, stream_size, level, &pl, nch);
     if (rc) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     char* ws = reinterpret_cast<char*>(d_workspace);
@@ -476,16 +508,27 @@ int fa_encode_i32_device_finish(int64_t n_stream, int64_t stream_size, uint32_t 
     if (rc) return rc;
     const int64_t* d_foff = reinterpret_cast<const int64_t*>(ws + pl.off_foff);
     hipLaunchKernelGGL(write_headers_kernel, dim3((unsigned)n_stream), dim3(256), 0, st, d_bytes, d_starts, d_foff, pl.nf,
-                       stream_size, (int32_t)pl.P.blocksize, (int32_t)pl.tail_bs);
+                       stream_size, (int32_t)pl.P.blocksize, (int32_t)pl.tail_bs, (int32_t)nch);
     int64_t nblk = (pl.F + 3) / 4;
     if (nblk > 8192) nblk = 8192;
     prof_begin(1, st);
     hipLaunchKernelGGL(compact_frames_kernel, dim3((unsigned)nblk), dim3(256), 0, st,
                        reinterpret_cast<const uint8_t*>(ws + pl.off_slots),
-                       reinterpret_cast<const uint32_t*>(ws + pl.off_fbytes), d_foff, d_starts, pl.nf, pl.F, crc, d_bytes);
+                       reinterpret_cast<const uint32_t*>(ws + pl.off_fbytes), d_foff, d_starts, pl.nf, pl.F, crc, d_bytes,
+                       pl.slot_stride);
     prof_end(1, st);
     FA_HIP_TRY(hipGetLastError());
     return FA_ERROR_NONE;
+}
+
+int fa_encode_i32_device_finish(int64_t n_stream, int64_t stream_size, uint32_t level, void* d_workspace,
+                                const int64_t* d_starts, unsigned char* d_bytes, void* stream) {
+    return encode_device_finish(1, n_stream, stream_size, level, d_workspace, d_starts, d_bytes, stream);
+}
+
+int fa_encode_i64_device_finish(int64_t n_stream, int64_t stream_size, uint32_t level, void* d_workspace,
+                                const int64_t* d_starts, unsigned char* d_bytes, void* stream) {
+    return encode_device_finish(2, n_stream, stream_size, level, d_workspace, d_starts, d_bytes, stream);
 }
 
 int fa_decode_i32_device(const unsigned char* d_bytes, int64_t n_bytes, const int64_t* d_starts,
@@ -584,7 +627,7 @@ int fa_int32_to_float32_device(const int32_t* d_input, int64_t n_stream, int64_t
 // Host-pointer drop-ins (reference C ABI).  Data makes a PCIe round trip; streams are processed
 // in chunks sized to the free HBM.
 // ---------------------------------------------------------------------------------------------
-static int encode_host(const int32_t* data, int64_t n_stream, int64_t stream_size, uint32_t level, int64_t* n_bytes,
+static int encode_host(const int32_t* data, int nch, int64_t n_stream, int64_t stream_size, uint32_t level, int64_t* n_bytes,
                        int64_t* starts, unsigned char** bytes) {
     if (level > 8) return FA_ERROR_INVALID_LEVEL;        // compress.c:144-146
     if (n_stream == 0) return FA_ERROR_ZERO_NSTREAM;     // compress.c:147-149
@@ -594,11 +637,11 @@ static int encode_host(const int32_t* data, int64_t n_stream, int64_t stream_siz
     for (int64_t i = 0; i < n_stream; ++i) starts[i] = 0;
     if (fa_device_count() <= 0) return FA_ERROR_DEVICE;
     EncodePlan one;
-    int rc = make_plan(1, stream_size, level, &one);
+    int rc = make_plan(1, stream_size, level, &one, nch);
     if (rc) return rc;
     size_t free_b = 0, total_b = 0;
     FA_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const size_t per_stream = (size_t)stream_size * 4 + 2 * one.total + 4096;
+    const size_t per_stream = (size_t)stream_size * 4 * (size_t)nch + 2 * one.total + 4096;
     int64_t chunk = (int64_t)((free_b / 10 * 8) / per_stream);
     if (chunk < 1) chunk = 1;
     if (chunk > n_stream) chunk = n_stream;
@@ -612,19 +655,20 @@ static int encode_host(const int32_t* data, int64_t n_stream, int64_t stream_siz
     int err = FA_ERROR_NONE;
     for (int64_t s0 = 0; s0 < n_stream && !err; s0 += chunk) {
         const int64_t ns = (n_stream - s0 < chunk) ? (n_stream - s0) : chunk;
-        const int64_t wsb = fa_encode_workspace_bytes(ns, stream_size, level);
+        const int64_t wsb = (nch == 2) ? fa_encode_workspace_bytes_i64(ns, stream_size, level) : fa_encode_workspace_bytes(ns, stream_size, level);
         void *d_in = nullptr, *d_ws = nullptr, *d_aux = nullptr, *d_out = nullptr;
-        if ((err = get_scratch(0, (size_t)ns * (size_t)stream_size * 4, &d_in))) break;
+        const size_t in_b = (size_t)ns * (size_t)stream_size * 4 * (size_t)nch;
+        if ((err = get_scratch(0, in_b, &d_in))) break;
         if ((err = get_scratch(5, (size_t)wsb, &d_ws))) break;
         if ((err = get_scratch(4, (size_t)ns * 16 + 512, &d_aux))) break;
         int64_t* d_starts = reinterpret_cast<int64_t*>(d_aux);
         int64_t* d_nb = d_starts + ns;
-        if (hipMemcpy(d_in, data + s0 * stream_size, (size_t)ns * (size_t)stream_size * 4, hipMemcpyHostToDevice) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
+        if (hipMemcpy(d_in, data + s0 * stream_size * nch, in_b, hipMemcpyHostToDevice) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
         int64_t total = 0;
-        err = fa_encode_i32_device_begin(reinterpret_cast<const int32_t*>(d_in), ns, stream_size, level, d_ws, wsb, d_starts, d_nb, &total, nullptr, nullptr);
+        err = encode_device_begin(reinterpret_cast<const int32_t*>(d_in), nch, ns, stream_size, level, d_ws, wsb, d_starts, d_nb, &total, nullptr, nullptr);
         if (err) break;
         if ((err = get_scratch(3, (size_t)total + 256, &d_out))) break;
-        err = fa_encode_i32_device_finish(ns, stream_size, level, d_ws, d_starts, reinterpret_cast<unsigned char*>(d_out), nullptr);
+        err = encode_device_finish(nch, ns, stream_size, level, d_ws, d_starts, reinterpret_cast<unsigned char*>(d_out), nullptr);
         if (err) break;
         unsigned char* hp = reinterpret_cast<unsigned char*>(std::malloc((size_t)total > 0 ? (size_t)total : 1));
         if (!hp) { err = FA_ERROR_ALLOC; break; }
@@ -655,12 +699,22 @@ static int encode_host(const int32_t* data, int64_t n_stream, int64_t stream_siz
 
 int encode_i32(int32_t* const data, int64_t n_stream, int64_t stream_size, uint32_t level, int64_t* n_bytes,
                int64_t* starts, unsigned char** bytes) {
-    return encode_host(data, n_stream, stream_size, level, n_bytes, starts, bytes);
+    return encode_host(data, 1, n_stream, stream_size, level, n_bytes, starts, bytes);
 }
 
 int encode_i32_threaded(int32_t* const data, int64_t n_stream, int64_t stream_size, uint32_t level, int64_t* n_bytes,
                         int64_t* starts, unsigned char** bytes) {
-    return encode_host(data, n_stream, stream_size, level, n_bytes, starts, bytes);
+    return encode_host(data, 1, n_stream, stream_size, level, n_bytes, starts, bytes);
+}
+
+int encode_i64(int64_t* const data, int64_t n_stream, int64_t stream_size, uint32_t level, int64_t* n_bytes,
+               int64_t* starts, unsigned char** bytes) {
+    return encode_host(reinterpret_cast<const int32_t*>(data), 2, n_stream, stream_size, level, n_bytes, starts, bytes);
+}
+
+int encode_i64_threaded(int64_t* const data, int64_t n_stream, int64_t stream_size, uint32_t level, int64_t* n_bytes,
+                        int64_t* starts, unsigned char** bytes) {
+    return encode_host(reinterpret_cast<const int32_t*>(data), 2, n_stream, stream_size, level, n_bytes, starts, bytes);
 }
 
 static int decode_host(const unsigned char* bytes, const int64_t* starts, const int64_t* nbytes, int64_t n_stream,

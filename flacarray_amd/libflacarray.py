@@ -71,9 +71,9 @@ def wrap_int32_to_float32(idata, n_stream, stream_size, offsets, gains):
     return output
 
 
-def _wrap_encode(fn, flatdata, n_stream, stream_size, level):
+def _wrap_encode(fn, flatdata, n_stream, stream_size, level, dtype=np.int32):
     _lib.require_device()
-    flatdata = np.ascontiguousarray(flatdata, dtype=np.int32)
+    flatdata = np.ascontiguousarray(flatdata, dtype=dtype)
     flat_starts = np.empty(n_stream, dtype=np.int64)
     flat_nbytes = np.empty(n_stream, dtype=np.int64)
     n_bytes = ctypes.c_int64(0)
@@ -124,7 +124,16 @@ def wrap_decode_i64(compressed, starts, nbytes, n_stream, stream_size, first_sam
     return wrap_decode_i32(compressed, starts, nbytes, n_stream, stream_size, first_sample, last_sample, use_threads, _i64=True)
 
 
-wrap_encode_i64 = wrap_encode_i64_threaded = _no_i64
+def wrap_encode_i64(flatdata, n_stream, stream_size, level):
+    """libflacarray.pyx:407-465"""
+    return _wrap_encode(_lib.lib().encode_i64, flatdata, n_stream, stream_size, level, dtype=np.int64)
+
+
+def wrap_encode_i64_threaded(flatdata, n_stream, stream_size, level):
+    """libflacarray.pyx:468-526"""
+    return _wrap_encode(_lib.lib().encode_i64_threaded, flatdata, n_stream, stream_size, level, dtype=np.int64)
+
+
 wrap_float64_to_int64 = wrap_int64_to_float64 = _no_i64
 
 
@@ -140,8 +149,7 @@ def encode_flac(data, level, use_threads=False):
         raise RuntimeError("Only C-contiguous arrays are supported")
     if level < 0 or level > 8:
         raise RuntimeError("FLAC only supports compression levels 0-8")
-    if data.dtype == flac_i64_dtype:
-        raise NotImplementedError(_NOT_I64)
+    is_i64 = data.dtype == flac_i64_dtype
     stream_size = data.shape[-1]
     if len(data.shape[:-1]) == 0:
         n_stream = 1
@@ -150,10 +158,11 @@ def encode_flac(data, level, use_threads=False):
         n_stream = int(np.prod(data.shape[:-1]))
         starts_shape = data.shape[:-1]
     flatdata = data.reshape((-1,))
-    if use_threads:
-        compressed, flatstarts, flatnbytes = wrap_encode_i32_threaded(flatdata, n_stream, stream_size, level)
+    if is_i64:
+        enc = wrap_encode_i64_threaded if use_threads else wrap_encode_i64
     else:
-        compressed, flatstarts, flatnbytes = wrap_encode_i32(flatdata, n_stream, stream_size, level)
+        enc = wrap_encode_i32_threaded if use_threads else wrap_encode_i32
+    compressed, flatstarts, flatnbytes = enc(flatdata, n_stream, stream_size, level)
     return (compressed, flatstarts.reshape(starts_shape), flatnbytes.reshape(starts_shape))
 
 
@@ -226,14 +235,14 @@ class EncodeWorkspace:
 
 
 def encode_flac_device(data, level=5, workspace=None, return_info=False):
-    """Encode a C-contiguous int32 CUDA tensor [..., stream_size] held in HBM.
+    """Encode a C-contiguous int32 (or int64: two-channel streams) CUDA tensor [..., stream_size] held in HBM.
 
     Returns (compressed uint8 tensor, starts int64 tensor, nbytes int64 tensor), all on the
     device, starts/nbytes with the leading shape of `data` (at least 1-D) -- the device-resident
     analogue of encode_flac (libflacarray.pyx:529-594).
     """
     torch = _torch()
-    if data.dtype != torch.int32:
+    if data.dtype != torch.int32 and data.dtype != torch.int64:
         raise RuntimeError("Only 32bit or 64bit integer data is supported")
     if not data.is_contiguous():
         raise RuntimeError("Only C-contiguous arrays are supported")
@@ -241,6 +250,7 @@ def encode_flac_device(data, level=5, workspace=None, return_info=False):
         raise RuntimeError("FLAC only supports compression levels 0-8")
     if not data.is_cuda:
         raise RuntimeError("encode_flac_device needs a tensor on the GPU")
+    i64 = data.dtype == torch.int64
     stream_size = data.shape[-1]
     if data.dim() == 1:
         n_stream, starts_shape = 1, (1,)
@@ -248,7 +258,7 @@ def encode_flac_device(data, level=5, workspace=None, return_info=False):
         n_stream = int(np.prod(data.shape[:-1]))
         starts_shape = tuple(data.shape[:-1])
     L = _lib.lib()
-    ws_bytes = L.fa_encode_workspace_bytes(n_stream, stream_size, level)
+    ws_bytes = (L.fa_encode_workspace_bytes_i64 if i64 else L.fa_encode_workspace_bytes)(n_stream, stream_size, level)
     if ws_bytes < 0:
         raise RuntimeError("Encoding failed, return code = 512")
     if workspace is None:
@@ -260,17 +270,17 @@ def encode_flac_device(data, level=5, workspace=None, return_info=False):
     if return_info:
         bs = 1152 if level <= 2 else 4096
         nf = (stream_size + bs - 1) // bs
-        info = torch.zeros((n_stream * nf, 8), dtype=torch.int32, device=data.device)
+        info = torch.zeros((n_stream * nf * (2 if i64 else 1), 8), dtype=torch.int32, device=data.device)
     total = ctypes.c_int64(0)
     with torch.cuda.device(data.device):
-        errcode = L.fa_encode_i32_device_begin(
+        errcode = (L.fa_encode_i64_device_begin if i64 else L.fa_encode_i32_device_begin)(
             _dp(data), n_stream, stream_size, level, _dp(ws), ws.numel(), _dp(starts), _dp(nbytes), ctypes.byref(total),
             _dp(info), _stream_ptr(),
         )
         if errcode != 0:
             raise RuntimeError(f"Encoding failed, return code = {errcode}")
         compressed = torch.empty(total.value, dtype=torch.uint8, device=data.device)
-        errcode = L.fa_encode_i32_device_finish(n_stream, stream_size, level, _dp(ws), _dp(starts), _dp(compressed), _stream_ptr())
+        errcode = (L.fa_encode_i64_device_finish if i64 else L.fa_encode_i32_device_finish)(n_stream, stream_size, level, _dp(ws), _dp(starts), _dp(compressed), _stream_ptr())
         if errcode != 0:
             raise RuntimeError(f"Encoding failed, return code = {errcode}")
     out = (compressed, starts.reshape(starts_shape), nbytes.reshape(starts_shape))

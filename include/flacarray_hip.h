@@ -58,6 +58,14 @@ int encode_i32_threaded(int32_t* const data, int64_t n_stream, int64_t stream_si
 int decode_i32(unsigned char* const bytes, int64_t* const starts, int64_t* const nbytes, int64_t n_stream,
                int64_t stream_size, int64_t first_sample, int64_t last_sample, int32_t* data, bool use_threads);
 
+/* replace encode_i64 / encode_i64_threaded, flacarray.h:229-247 (compress.c:482-540): int64 samples
+ * as two-channel 32-bit streams, channel 0 = low word, channel 1 = high word (utils.c:96-123); the
+ * channels are coded independently (channel assignment "left/right") */
+int encode_i64(int64_t* const data, int64_t n_stream, int64_t stream_size, uint32_t level, int64_t* n_bytes,
+               int64_t* starts, unsigned char** bytes);
+int encode_i64_threaded(int64_t* const data, int64_t n_stream, int64_t stream_size, uint32_t level, int64_t* n_bytes,
+                        int64_t* starts, unsigned char** bytes);
+
 /* replaces decode_i64, flacarray.h:261-271 (decompress.c:343-375): two-channel streams, int64
  * sample = (channel 1 << 32) | (channel 0 as unsigned) (utils.c:96-123).  Reads streams with any
  * stereo channel assignment (left/right, left/side, side/right, mid/side). */
@@ -91,6 +99,15 @@ int fa_encode_i32_device_begin(const int32_t* d_data, int64_t n_stream, int64_t 
 /* Encode, phase 2: assemble the blob (stream headers, byte-exact concatenation, CRC-16) into
  * d_bytes[*h_total_bytes].  Same arguments as phase 1. */
 int fa_encode_i32_device_finish(int64_t n_stream, int64_t stream_size, uint32_t level, void* d_workspace,
+                                const int64_t* d_starts, unsigned char* d_bytes, void* stream);
+
+/* The same three calls for int64 input (two-channel streams); d_info, if given, holds one
+ * FrameInfo per SUBFRAME: [ (stream * frames + frame) * 2 + channel ]. */
+int64_t fa_encode_workspace_bytes_i64(int64_t n_stream, int64_t stream_size, uint32_t level);
+int fa_encode_i64_device_begin(const int64_t* d_data, int64_t n_stream, int64_t stream_size, uint32_t level,
+                               void* d_workspace, int64_t workspace_bytes, int64_t* d_starts, int64_t* d_nbytes,
+                               int64_t* h_total_bytes, int32_t* d_info, void* stream);
+int fa_encode_i64_device_finish(int64_t n_stream, int64_t stream_size, uint32_t level, void* d_workspace,
                                 const int64_t* d_starts, unsigned char* d_bytes, void* stream);
 
 /* Decode [first_sample,last_sample) (or everything when either is negative) of n_stream
