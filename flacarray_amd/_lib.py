@@ -17,6 +17,8 @@ SYMBOLS = [
     "decode_i64",
     "encode_i64",
     "encode_i64_threaded",
+    "float64_to_int64",
+    "int64_to_float64",
     "float32_to_int32",
     "int32_to_float32",
     "fa_encode_workspace_bytes",
@@ -28,6 +30,8 @@ SYMBOLS = [
     "fa_encode_workspace_bytes_i64",
     "fa_encode_i64_device_begin",
     "fa_encode_i64_device_finish",
+    "fa_float64_to_int64_device",
+    "fa_int64_to_float64_device",
     "fa_decode_slices_i64_device",
     "fa_float32_to_int32_device",
     "fa_int32_to_float32_device",
@@ -115,6 +119,14 @@ def _declare_i64(L):
     for name in ("encode_i64", "encode_i64_threaded"):
         getattr(L, name).argtypes = L.encode_i32.argtypes
         getattr(L, name).restype = cint
+    L.float64_to_int64.argtypes = L.float32_to_int32.argtypes
+    L.float64_to_int64.restype = cint
+    L.int64_to_float64.argtypes = L.int32_to_float32.argtypes
+    L.int64_to_float64.restype = None
+    L.fa_float64_to_int64_device.argtypes = L.fa_float32_to_int32_device.argtypes
+    L.fa_float64_to_int64_device.restype = cint
+    L.fa_int64_to_float64_device.argtypes = L.fa_int32_to_float32_device.argtypes
+    L.fa_int64_to_float64_device.restype = cint
     L.fa_encode_workspace_bytes_i64.argtypes = L.fa_encode_workspace_bytes.argtypes
     L.fa_encode_workspace_bytes_i64.restype = ctypes.c_int64
     L.fa_encode_i64_device_begin.argtypes = L.fa_encode_i32_device_begin.argtypes

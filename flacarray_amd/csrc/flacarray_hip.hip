@@ -623,6 +623,36 @@ int fa_int32_to_float32_device(const int32_t* d_input, int64_t n_stream, int64_t
     return FA_ERROR_NONE;
 }
 
+int fa_float64_to_int64_device(const double* d_input, int64_t n_stream, int64_t stream_size, const double* d_quanta,
+                               int64_t* d_output, double* d_offsets, double* d_gains, void* stream) {
+    if (n_stream <= 0) return FA_ERROR_ZERO_NSTREAM;
+    if (stream_size <= 0) return FA_ERROR_ZERO_STREAMSIZE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    void* p = nullptr;
+    int rc = get_scratch(4, 256, &p);
+    if (rc) return rc;
+    int* d_flags = reinterpret_cast<int*>(p);
+    FA_HIP_TRY(hipMemsetAsync(d_flags, 0, 4, st));
+    hipLaunchKernelGGL(float64_to_int64_kernel, dim3((unsigned)n_stream), dim3(1024), 0, st, d_input, stream_size, d_quanta,
+                       d_output, d_offsets, d_gains, d_flags);
+    int h = 0;
+    FA_HIP_TRY(hipMemcpyAsync(&h, d_flags, 4, hipMemcpyDeviceToHost, st));
+    FA_HIP_TRY(hipStreamSynchronize(st));
+    FA_HIP_TRY(hipGetLastError());
+    return (h & 1) ? FA_ERROR_NAN_INPUT : FA_ERROR_NONE;
+}
+
+int fa_int64_to_float64_device(const int64_t* d_input, int64_t n_stream, int64_t stream_size, const double* d_offsets,
+                               const double* d_gains, double* d_output, void* stream) {
+    if (n_stream <= 0 || stream_size <= 0) return FA_ERROR_NONE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t cps = (stream_size + kDequantChunk - 1) / kDequantChunk;
+    hipLaunchKernelGGL(int64_to_float64_kernel, dim3((unsigned)(n_stream * cps)), dim3(256), 0, st, d_input, stream_size, cps,
+                       d_offsets, d_gains, d_output);
+    FA_HIP_TRY(hipGetLastError());
+    return FA_ERROR_NONE;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Host-pointer drop-ins (reference C ABI).  Data makes a PCIe round trip; streams are processed
 // in chunks sized to the free HBM.
@@ -838,6 +868,71 @@ void int32_to_float32(int32_t const* input, int64_t n_stream, int64_t stream_siz
         ok = ok && hipMemcpy(output + s0 * stream_size, d_out, nb, hipMemcpyDeviceToHost) == hipSuccess;
         if (!ok) {
             std::fprintf(stderr, "flacarray_hip: int32_to_float32 device failure\n");
+            std::abort();
+        }
+    }
+}
+
+int float64_to_int64(double const* input, int64_t n_stream, int64_t stream_size, double const* quanta, int64_t* output,
+                     double* offsets, double* gains) {
+    if (n_stream <= 0 || stream_size <= 0) return FA_ERROR_NONE;
+    if (fa_device_count() <= 0) return FA_ERROR_DEVICE;
+    size_t free_b = 0, total_b = 0;
+    FA_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    int64_t chunk = (int64_t)((free_b / 10 * 8) / ((size_t)stream_size * 16 + 64));
+    if (chunk < 1) chunk = 1;
+    if (chunk > n_stream) chunk = n_stream;
+    int err = FA_ERROR_NONE;
+    for (int64_t s0 = 0; s0 < n_stream && !err; s0 += chunk) {
+        const int64_t ns = (n_stream - s0 < chunk) ? (n_stream - s0) : chunk;
+        const size_t nb = (size_t)ns * (size_t)stream_size * 8;
+        void *d_in = nullptr, *d_out = nullptr, *d_aux = nullptr;
+        if ((err = get_scratch(0, nb, &d_in))) break;
+        if ((err = get_scratch(5, nb, &d_out))) break;
+        if ((err = get_scratch(3, (size_t)ns * 24 + 768, &d_aux))) break;
+        double* d_q = reinterpret_cast<double*>(d_aux);
+        double* d_off = d_q + ns;
+        double* d_gain = d_off + ns;
+        if (hipMemcpy(d_in, input + s0 * stream_size, nb, hipMemcpyHostToDevice) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
+        if (quanta && hipMemcpy(d_q, quanta + s0, (size_t)ns * 8, hipMemcpyHostToDevice) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
+        err = fa_float64_to_int64_device(reinterpret_cast<const double*>(d_in), ns, stream_size, quanta ? d_q : nullptr,
+                                         reinterpret_cast<int64_t*>(d_out), d_off, d_gain, nullptr);
+        if (err) break;
+        if (hipMemcpy(output + s0 * stream_size, d_out, nb, hipMemcpyDeviceToHost) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
+        if (hipMemcpy(offsets + s0, d_off, (size_t)ns * 8, hipMemcpyDeviceToHost) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
+        if (hipMemcpy(gains + s0, d_gain, (size_t)ns * 8, hipMemcpyDeviceToHost) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
+    }
+    return err;
+}
+
+void int64_to_float64(int64_t const* input, int64_t n_stream, int64_t stream_size, double const* offsets,
+                      double const* gains, double* output) {
+    if (n_stream <= 0 || stream_size <= 0) return;
+    if (fa_device_count() <= 0) {
+        std::fprintf(stderr, "flacarray_hip: int64_to_float64 called without a HIP device\n");
+        std::abort();  // the reference signature has no error channel; never fall back silently
+    }
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) std::abort();
+    int64_t chunk = (int64_t)((free_b / 10 * 8) / ((size_t)stream_size * 16 + 64));
+    if (chunk < 1) chunk = 1;
+    if (chunk > n_stream) chunk = n_stream;
+    for (int64_t s0 = 0; s0 < n_stream; s0 += chunk) {
+        const int64_t ns = (n_stream - s0 < chunk) ? (n_stream - s0) : chunk;
+        const size_t nb = (size_t)ns * (size_t)stream_size * 8;
+        void *d_in = nullptr, *d_out = nullptr, *d_aux = nullptr;
+        if (get_scratch(0, nb, &d_in) || get_scratch(5, nb, &d_out) || get_scratch(3, (size_t)ns * 16 + 512, &d_aux)) std::abort();
+        double* d_off = reinterpret_cast<double*>(d_aux);
+        double* d_gain = d_off + ns;
+        bool ok = hipMemcpy(d_in, input + s0 * stream_size, nb, hipMemcpyHostToDevice) == hipSuccess;
+        ok = ok && hipMemcpy(d_off, offsets + s0, (size_t)ns * 8, hipMemcpyHostToDevice) == hipSuccess;
+        ok = ok && hipMemcpy(d_gain, gains + s0, (size_t)ns * 8, hipMemcpyHostToDevice) == hipSuccess;
+        ok = ok && fa_int64_to_float64_device(reinterpret_cast<const int64_t*>(d_in), ns, stream_size, d_off, d_gain,
+                                              reinterpret_cast<double*>(d_out), nullptr) == FA_ERROR_NONE;
+        ok = ok && hipStreamSynchronize(nullptr) == hipSuccess;
+        ok = ok && hipMemcpy(output + s0 * stream_size, d_out, nb, hipMemcpyDeviceToHost) == hipSuccess;
+        if (!ok) {
+            std::fprintf(stderr, "flacarray_hip: int64_to_float64 device failure\n");
             std::abort();
         }
     }

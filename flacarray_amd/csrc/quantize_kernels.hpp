@@ -139,4 +139,85 @@ __global__ __launch_bounds__(256) void int32_to_float32_kernel(const int32_t* __
     for (int64_t i = lo + 4 * n4 + threadIdx.x; i < hi; i += 256) out[i] = __fadd_rn(off, __fmul_rn(coeff, (float)in[i]));
 }
 
+// ---- float64 <-> int64 (utils.c:245-348): every operation is a double operation ------------------
+__global__ __launch_bounds__(1024) void float64_to_int64_kernel(const double* __restrict__ input, int64_t stream_size,
+                                                                const double* __restrict__ quanta, int64_t* __restrict__ output,
+                                                                double* __restrict__ offsets, double* __restrict__ gains,
+                                                                int* __restrict__ flags) {
+    __shared__ double s_min[16], s_max[16];
+    __shared__ double s_off, s_gain;
+    __shared__ int s_nan;
+    const int64_t is = blockIdx.x;
+    const double* in = input + is * stream_size;
+    int64_t* out = output + is * stream_size;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_nan = 0;
+    double mn = in[0], mx = in[0];
+    bool nan = false;
+    const bool vec = ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
+    const int64_t n2 = vec ? (stream_size >> 1) : 0;
+    for (int64_t i = tid; i < n2; i += 1024) {
+        const double2 v = reinterpret_cast<const double2*>(in)[i];
+        nan = nan || (v.x != v.x) || (v.y != v.y);
+        mn = (v.x < mn) ? v.x : mn; mx = (v.x > mx) ? v.x : mx;
+        mn = (v.y < mn) ? v.y : mn; mx = (v.y > mx) ? v.y : mx;
+    }
+    for (int64_t i = 2 * n2 + tid; i < stream_size; i += 1024) {
+        const double v = in[i];
+        nan = nan || (v != v);
+        mn = (v < mn) ? v : mn;
+        mx = (v > mx) ? v : mx;
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double a = __shfl_xor(mn, off, 64), b = __shfl_xor(mx, off, 64);
+        mn = (a < mn) ? a : mn;
+        mx = (b > mx) ? b : mx;
+    }
+    __syncthreads();
+    if (nan) s_nan = 1;
+    if ((tid & 63) == 0) { s_min[tid >> 6] = mn; s_max[tid >> 6] = mx; }
+    __syncthreads();
+    if (tid == 0) {
+        double smin = s_min[0], smax = s_max[0];
+        for (int w = 1; w < 16; ++w) {
+            smin = (s_min[w] < smin) ? s_min[w] : smin;
+            smax = (s_max[w] > smax) ? s_max[w] : smax;
+        }
+        if (s_nan) atomicOr(flags, 1);
+        double off = 0.5 * (smin + smax);                                             // utils.c:278
+        const double amp = ((smin - off) > (smax - off)) ? 1.01 * (smin - off) : 1.01 * (smax - off);  // :282-286
+        const double min_quanta = amp / 9223372036854775808.0;                        // :287 (double)(2^63 - 1) == 2^63
+        const double sq = quanta ? quanta[is] : min_quanta;
+        const int64_t nquant = x86_cvtt_i64(off / sq);                                // :305
+        off = sq * (double)nquant;                                                    // :306
+        const double gain = (sq == 0.0) ? 1.0 : 1.0 / sq;                             // :308-314
+        offsets[is] = off;
+        gains[is] = gain;
+        s_off = off;
+        s_gain = gain;
+    }
+    __syncthreads();
+    const double off = s_off, gain = s_gain;
+    for (int64_t i = tid; i < stream_size; i += 1024) {
+        const double t = in[i] - off;
+        out[i] = (t >= 0.0) ? x86_cvtt_i64(gain * t + 0.5) : x86_cvtt_i64(gain * t - 0.5);  // :316-323
+    }
+}
+
+__global__ __launch_bounds__(256) void int64_to_float64_kernel(const int64_t* __restrict__ input, int64_t stream_size,
+                                                               int64_t chunks_per_stream, const double* __restrict__ offsets,
+                                                               const double* __restrict__ gains, double* __restrict__ output) {
+    const int64_t is = blockIdx.x / chunks_per_stream;
+    const int64_t ck = blockIdx.x - is * chunks_per_stream;
+    const double off = offsets[is];
+    const double coeff = 1.0 / gains[is];                                             // utils.c:340
+    const int64_t lo = ck * kDequantChunk;
+    int64_t hi = lo + kDequantChunk;
+    if (hi > stream_size) hi = stream_size;
+    const int64_t* in = input + is * stream_size;
+    double* out = output + is * stream_size;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) out[i] = off + coeff * (double)in[i];  // :343
+}
+
 }  // namespace fa

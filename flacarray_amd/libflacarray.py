@@ -6,8 +6,9 @@ Mirrors src/flacarray/libflacarray/libflacarray.pyx of the reference: `encode_fl
 shapes/dtypes and error text.  numpy in / numpy out goes through the host-pointer C entry
 points; the `*_device` functions at the bottom take torch tensors already resident in HBM.
 
-The int64 / float64 twins (2-channel streams) are outside this hot path and raise
-NotImplementedError.
+The int64 / float64 twins (`wrap_encode_i64[_threaded]` :407/:468, `wrap_decode_i64` :656,
+`wrap_float64_to_int64` :164, `wrap_int64_to_float64` :250) run the two-channel variants of the
+same kernels.
 """
 import ctypes
 import weakref
@@ -21,7 +22,6 @@ flac_i64_dtype = np.dtype(np.int64)
 compressed_dtype = np.dtype(np.uint8)
 offset_dtype = np.dtype(np.int64)
 
-_NOT_I64 = "the int64/float64 (2-channel) path is not part of the MI355X hot path"
 
 
 def _ptr(a):
@@ -39,18 +39,19 @@ def _adopt_malloc(addr, n):
     return arr
 
 
-def wrap_float32_to_int32(flatdata, n_stream, stream_size, quanta):
+def wrap_float32_to_int32(flatdata, n_stream, stream_size, quanta, _f64=False):
     """libflacarray.pyx:113-161.  `quanta` is used only if len(quanta) == n_stream."""
     _lib.require_device()
-    flatdata = np.ascontiguousarray(flatdata, dtype=np.float32)
+    ft, it = (np.float64, np.int64) if _f64 else (np.float32, np.int32)
+    flatdata = np.ascontiguousarray(flatdata, dtype=ft)
     size = n_stream * stream_size
-    output = np.empty(size, dtype=np.int32)
-    offsets = np.empty(n_stream, dtype=np.float32)
-    gains = np.empty(n_stream, dtype=np.float32)
+    output = np.empty(size, dtype=it)
+    offsets = np.empty(n_stream, dtype=ft)
+    gains = np.empty(n_stream, dtype=ft)
     q = None
     if len(quanta) == n_stream:
-        q = np.ascontiguousarray(quanta, dtype=np.float32)
-    errcode = _lib.lib().float32_to_int32(
+        q = np.ascontiguousarray(quanta, dtype=ft)
+    errcode = (_lib.lib().float64_to_int64 if _f64 else _lib.lib().float32_to_int32)(
         _ptr(flatdata), n_stream, stream_size, _ptr(q) if q is not None else None, _ptr(output), _ptr(offsets), _ptr(gains)
     )
     if errcode & _lib.ERROR_NAN_INPUT:
@@ -60,15 +61,28 @@ def wrap_float32_to_int32(flatdata, n_stream, stream_size, quanta):
     return (output, offsets, gains)
 
 
-def wrap_int32_to_float32(idata, n_stream, stream_size, offsets, gains):
+def wrap_int32_to_float32(idata, n_stream, stream_size, offsets, gains, _f64=False):
     """libflacarray.pyx:215-247"""
     _lib.require_device()
-    idata = np.ascontiguousarray(idata, dtype=np.int32)
-    offsets = np.ascontiguousarray(offsets, dtype=np.float32)
-    gains = np.ascontiguousarray(gains, dtype=np.float32)
-    output = np.empty(n_stream * stream_size, dtype=np.float32)
-    _lib.lib().int32_to_float32(_ptr(idata), n_stream, stream_size, _ptr(offsets), _ptr(gains), _ptr(output))
+    ft, it = (np.float64, np.int64) if _f64 else (np.float32, np.int32)
+    idata = np.ascontiguousarray(idata, dtype=it)
+    offsets = np.ascontiguousarray(offsets, dtype=ft)
+    gains = np.ascontiguousarray(gains, dtype=ft)
+    output = np.empty(n_stream * stream_size, dtype=ft)
+    (_lib.lib().int64_to_float64 if _f64 else _lib.lib().int32_to_float32)(
+        _ptr(idata), n_stream, stream_size, _ptr(offsets), _ptr(gains), _ptr(output)
+    )
     return output
+
+
+def wrap_float64_to_int64(flatdata, n_stream, stream_size, quanta):
+    """libflacarray.pyx:164-212"""
+    return wrap_float32_to_int32(flatdata, n_stream, stream_size, quanta, _f64=True)
+
+
+def wrap_int64_to_float64(idata, n_stream, stream_size, offsets, gains):
+    """libflacarray.pyx:250-282"""
+    return wrap_int32_to_float32(idata, n_stream, stream_size, offsets, gains, _f64=True)
 
 
 def _wrap_encode(fn, flatdata, n_stream, stream_size, level, dtype=np.int32):
@@ -115,10 +129,6 @@ def wrap_decode_i32(compressed, starts, nbytes, n_stream, stream_size, first_sam
     return output
 
 
-def _no_i64(*args, **kwargs):
-    raise NotImplementedError(_NOT_I64)
-
-
 def wrap_decode_i64(compressed, starts, nbytes, n_stream, stream_size, first_sample, last_sample, use_threads):
     """libflacarray.pyx:656-710"""
     return wrap_decode_i32(compressed, starts, nbytes, n_stream, stream_size, first_sample, last_sample, use_threads, _i64=True)
@@ -134,7 +144,7 @@ def wrap_encode_i64_threaded(flatdata, n_stream, stream_size, level):
     return _wrap_encode(_lib.lib().encode_i64_threaded, flatdata, n_stream, stream_size, level, dtype=np.int64)
 
 
-wrap_float64_to_int64 = wrap_int64_to_float64 = _no_i64
+
 
 
 def encode_flac(data, level, use_threads=False):

@@ -9,14 +9,13 @@ import os
 
 import numpy as np
 
-from .libflacarray import wrap_float32_to_int32, wrap_int32_to_float32
+from .libflacarray import wrap_float32_to_int32, wrap_float64_to_int64, wrap_int32_to_float32, wrap_int64_to_float64
 
 log = logging.getLogger("flacarray")
 _lvl = os.environ.get("FLACARRAY_LOGLEVEL", os.environ.get("FLACARRAY_LOG_LEVEL"))
 if _lvl is not None and hasattr(logging, _lvl):
     log.setLevel(getattr(logging, _lvl))
 
-_NOT_F64 = "the int64/float64 (2-channel) path is not part of the MI355X hot path"
 
 
 def function_timer(f):
@@ -58,8 +57,7 @@ def float_to_int(data, quanta=None, precision=None):
         raise RuntimeError("Cannot specify both quanta and precision")
     if data.dtype != np.dtype(np.float32) and data.dtype != np.dtype(np.float64):
         raise ValueError("Only float32 and float64 data are supported")
-    if data.dtype == np.dtype(np.float64):
-        raise NotImplementedError(_NOT_F64)
+    is_f64 = data.dtype == np.dtype(np.float64)
 
     leading_shape = data.shape[:-1]
     n_stream = 1 if len(leading_shape) == 0 else int(np.prod(leading_shape))
@@ -88,7 +86,7 @@ def float_to_int(data, quanta=None, precision=None):
     else:
         quanta = quanta * np.ones(leading_shape, dtype=data.dtype)
 
-    output, offsets, gains = wrap_float32_to_int32(
+    output, offsets, gains = (wrap_float64_to_int64 if is_f64 else wrap_float32_to_int32)(
         np.ascontiguousarray(data).reshape((-1,)), n_stream, stream_size, np.asarray(quanta).reshape((-1,)).astype(data.dtype)
     )
     if len(leading_shape) == 0:
@@ -100,13 +98,13 @@ def int_to_float(idata, offset, gain):
     """Restore float32 data from int32 (utils.py:346-408)."""
     if idata.dtype != np.dtype(np.int32) and idata.dtype != np.dtype(np.int64):
         raise ValueError("Input data should be int32 or int64")
-    if idata.dtype == np.dtype(np.int64):
-        raise NotImplementedError(_NOT_F64)
+    is_i64 = idata.dtype == np.dtype(np.int64)
+    ftype = np.float64 if is_i64 else np.float32
     leading_shape = idata.shape[:-1]
     if len(leading_shape) == 0 or (len(leading_shape) == 1 and leading_shape[0] == 1):
         n_stream = 1
-        offset = ensure_one_element(offset, np.float32)
-        gain = ensure_one_element(gain, np.float32)
+        offset = ensure_one_element(offset, ftype)
+        gain = ensure_one_element(gain, ftype)
     else:
         n_stream = int(np.prod(leading_shape))
         if offset.shape != leading_shape:
@@ -114,7 +112,7 @@ def int_to_float(idata, offset, gain):
         if gain.shape != leading_shape:
             raise ValueError(f"Gain array has shape {gain.shape}, expected shape {leading_shape}")
     stream_size = idata.shape[-1]
-    result = wrap_int32_to_float32(
+    result = (wrap_int64_to_float64 if is_i64 else wrap_int32_to_float32)(
         np.ascontiguousarray(idata).reshape((-1,)), n_stream, stream_size, offset.reshape((-1,)), gain.reshape((-1,))
     )
     return result.reshape(idata.shape)

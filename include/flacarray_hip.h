@@ -81,6 +81,12 @@ int float32_to_int32(float const* input, int64_t n_stream, int64_t stream_size, 
 void int32_to_float32(int32_t const* input, int64_t n_stream, int64_t stream_size, float const* offsets,
                       float const* gains, float* output);
 
+/* replace float64_to_int64 / int64_to_float64, flacarray.h:285-302 (utils.c:245-348) */
+int float64_to_int64(double const* input, int64_t n_stream, int64_t stream_size, double const* quanta, int64_t* output,
+                     double* offsets, double* gains);
+void int64_to_float64(int64_t const* input, int64_t n_stream, int64_t stream_size, double const* offsets,
+                      double const* gains, double* output);
+
 /* ---------------------------------------------------------------------------------------
  * Group 2: device-pointer entry points (every pointer named d_* is HBM memory)
  * ------------------------------------------------------------------------------------- */
@@ -149,6 +155,12 @@ int fa_float32_to_int32_device(const float* d_input, int64_t n_stream, int64_t s
 
 int fa_int32_to_float32_device(const int32_t* d_input, int64_t n_stream, int64_t stream_size, const float* d_offsets,
                                const float* d_gains, float* d_output, void* stream);
+
+/* The float64 <-> int64 twins (utils.c:245-348) on device pointers. */
+int fa_float64_to_int64_device(const double* d_input, int64_t n_stream, int64_t stream_size, const double* d_quanta,
+                               int64_t* d_output, double* d_offsets, double* d_gains, void* stream);
+int fa_int64_to_float64_device(const int64_t* d_input, int64_t n_stream, int64_t stream_size, const double* d_offsets,
+                               const double* d_gains, double* d_output, void* stream);
 
 /* Kernel timing for bench.py: when enabled, HIP events are recorded on the launch stream around
  * the three dominant kernels of the most recent calls; fa_profile_last waits for them and
