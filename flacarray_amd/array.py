@@ -346,7 +346,9 @@ class FlacArray:
         if self._stream_offsets is not None:
             off = torch.from_numpy(np.ascontiguousarray(self._stream_offsets).reshape(-1))
             gain = torch.from_numpy(np.ascontiguousarray(self._stream_gains).reshape(-1))
-        out, out_off = decode_slices_device(comp, st, nb, self._stream_size, streams, first, count, offsets=off, gains=gain)
+        out, out_off = decode_slices_device(
+            comp, st, nb, self._stream_size, streams, first, count, offsets=off, gains=gain, is_int64=self._is_int64
+        )
         flat = out.cpu().numpy()
         count = np.asarray(count, dtype=np.int64)
         return [flat[o : o + c] for o, c in zip(out_off, count)]

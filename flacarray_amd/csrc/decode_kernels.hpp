@@ -1013,9 +1013,18 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
             double radd = 0.0;  // NCH == 2: what a 33-bit VERBATIM sample adds to its low word
             if (__builtin_expect(!__all(fastok), 0)) {
                 if (!fastok) {
-                    if (escw == 0) {
+                    if (escw < 0 && z < 32 && ((nbp + 128u) >> kChunkShift) < next_chunk) {
+                        // a Rice code of 33..63 bits whose stop bit lies inside the window and whose
+                        // successor's window is resident: r and nbp above are already right (the
+                        // 32-bit limit of `fastok` only budgets the top-up, it is not a decoding limit)
+                    } else if (escw == 0) {
                         r = 0;
                         nbp = bitpos;
+                    } else if (escw > 0 && escw <= 32) {
+                        // fixed-width sample (escaped partition, VERBATIM subframe): at most 32 bits,
+                        // which the window already holds and the top-up budget covers
+                        r = (int32_t)A >> (32 - escw);
+                        nbp = bitpos + (uint32_t)escw;
                     } else if (NCH == 2 && escw > 32) {
                         const BitsRet t1 = slow_get(cbase, lim16, ring, bitpos, next_chunk, 1);
                         const BitsRet t2 = slow_get(cbase, lim16, ring, t1.bitpos, t1.next_chunk, 32);

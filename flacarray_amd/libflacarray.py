@@ -369,7 +369,8 @@ def decode_flac_device(compressed, starts, nbytes, stream_size, first_sample=-1,
     return out
 
 
-def decode_slices_device(compressed, starts, nbytes, stream_size, slice_stream, slice_first, slice_count, offsets=None, gains=None):
+def decode_slices_device(compressed, starts, nbytes, stream_size, slice_stream, slice_first, slice_count, offsets=None, gains=None,
+                         is_int64=False):
     """Batched random access: slice i = samples [first[i], first[i]+count[i]) of (flat) stream
     slice_stream[i].  Returns (flat output tensor, int64 numpy array of output offsets).  The
     reference needs one decode call per slice (decompress.py:42-48)."""
@@ -386,13 +387,14 @@ def decode_slices_device(compressed, starts, nbytes, stream_size, slice_stream, 
     n_stream = int(np.prod(starts.shape))
     L = _lib.lib()
     f32 = offsets is not None
-    out = torch.empty(total, dtype=torch.float32 if f32 else torch.int32, device=dev)
+    ft, it = (torch.float64, torch.int64) if is_int64 else (torch.float32, torch.int32)
+    out = torch.empty(total, dtype=ft if f32 else it, device=dev)
     if f32:
-        # per-task gains/offsets are looked up per slice on the host side
-        soff = offsets.reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
-        sgain = gains.reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
+        # per-stream offsets / gains; the kernel looks them up by the slice's stream
+        soff = offsets.reshape(-1).to(device=dev, dtype=ft).contiguous()
+        sgain = gains.reshape(-1).to(device=dev, dtype=ft).contiguous()
     with torch.cuda.device(dev):
-        errcode = L.fa_decode_slices_i32_device(
+        errcode = (L.fa_decode_slices_i64_device if is_int64 else L.fa_decode_slices_i32_device)(
             _dp(compressed), compressed.numel(), _dp(starts), _dp(nbytes), n_stream, stream_size, n,
             ctypes.c_void_p(slice_stream.ctypes.data), ctypes.c_void_p(slice_first.ctypes.data),
             ctypes.c_void_p(slice_count.ctypes.data), ctypes.c_void_p(out_off.ctypes.data),

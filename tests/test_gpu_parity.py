@@ -512,3 +512,15 @@ def test_int64_float64_array_path(fa, oracle):
     g2 = FakeH5Group()
     H.write_array(xi, g2)
     assert np.array_equal(H.read_array(g2), xi)
+
+
+def test_read_slices_batched_int64(fa):
+    rng = np.random.default_rng(17)
+    x = (np.cumsum(rng.integers(-(2**35), 2**35, (5, 20000)), axis=-1)).astype(np.int64)
+    fl = fa.FlacArray.from_array(x)
+    streams = rng.integers(0, 5, 200)
+    count = rng.integers(1, 6000, 200)
+    first = np.array([rng.integers(0, 20000 - c + 1) for c in count])
+    got = fl.read_slices(streams, first, count)
+    for s_, f_, c_, g_ in zip(streams, first, count, got):
+        assert g_.dtype == np.int64 and np.array_equal(g_, x[s_, f_ : f_ + c_])
