@@ -232,6 +232,9 @@ def main():
                 "algorithmic_bytes_per_sample": round(4 + c_bytes, 4),
             },
             "kernels": kernels,
+            # each direction on its own (kernel time of K3+K5 / of K7, HIP events on the launch stream)
+            "encode_Msamples_per_s": round(n_local * world / ((enc + cmpm) * 1e-3) / 1e6, 1),
+            "decode_Msamples_per_s": round(n_local * world / (dec * 1e-3) / 1e6, 1),
         }
         if gather_s is not None:
             out["allgatherv_s"] = round(gather_s, 4)
