@@ -421,3 +421,12 @@ class FlacArray:
             mpi_comm=None,
             mpi_dist=None,
         )
+
+    def write_zarr(self, zgrp):
+        """Write the compressed representation to an open Zarr group (array.py:766-804); same schema as HDF5."""
+        self.write_hdf5(zgrp)
+
+    @classmethod
+    def read_zarr(cls, zgrp, keep=None, mpi_comm=None, mpi_dist=None, no_flatten=False):
+        """Construct a FlacArray from a Zarr group (array.py:806-884)."""
+        return cls.read_hdf5(zgrp, keep=keep, mpi_comm=mpi_comm, mpi_dist=mpi_dist, no_flatten=no_flatten)

@@ -38,6 +38,14 @@ def _no_mpi(mpi_comm):
         )
 
 
+def _create(grp, name, shape, dtype):
+    """h5py.Group / zarr-2 Group: create_dataset; zarr-3 Group: create_array (zarr.py:236-241)."""
+    shape = tuple(int(x) for x in shape)
+    if hasattr(grp, "create_array"):
+        return grp.create_array(name, shape=shape, dtype=dtype)
+    return grp.create_dataset(name, shape=shape, dtype=dtype)
+
+
 def _one_element(arr, dtype):
     return np.asarray(arr, dtype=dtype).reshape(-1) if np.ndim(arr) == 0 else np.asarray(arr, dtype=dtype)
 
@@ -75,20 +83,20 @@ def write_compressed(
     hgrp.attrs["flacarray_software_version"] = _version
     hgrp.attrs[hdf5_names["flac_channels"]] = f"{int(n_channels)}"
 
-    dstarts = hgrp.create_dataset(hdf5_names["stream_starts"], shape, dtype=np.int64)
+    dstarts = _create(hgrp, hdf5_names["stream_starts"], shape, np.int64)
     dstarts.attrs[hdf5_names["stream_size"]] = int(stream_size)
     dstarts[...] = starts
-    dbytes = hgrp.create_dataset(hdf5_names["stream_bytes"], shape, dtype=np.int64)
+    dbytes = _create(hgrp, hdf5_names["stream_bytes"], shape, np.int64)
     dbytes[...] = nbytes
     if stream_offsets is not None:
         off = _one_element(stream_offsets, fdt).reshape(shape)
-        d = hgrp.create_dataset(hdf5_names["stream_offsets"], shape, dtype=off.dtype)
+        d = _create(hgrp, hdf5_names["stream_offsets"], shape, off.dtype)
         d[...] = off
     if stream_gains is not None:
         gn = _one_element(stream_gains, fdt).reshape(shape)
-        d = hgrp.create_dataset(hdf5_names["stream_gains"], shape, dtype=gn.dtype)
+        d = _create(hgrp, hdf5_names["stream_gains"], shape, gn.dtype)
         d[...] = gn
-    dcomp = hgrp.create_dataset(hdf5_names["compressed"], (comp.shape[0],), dtype=np.uint8)
+    dcomp = _create(hgrp, hdf5_names["compressed"], (comp.shape[0],), np.uint8)
     dcomp[...] = comp
 
 

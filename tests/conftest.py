@@ -108,3 +108,15 @@ class FakeH5Group(dict):
     def create_dataset(self, name, shape, dtype=None):
         self[name] = FakeH5Dataset(shape, dtype)
         return self[name]
+
+
+class FakeZarr3Group(dict):
+    """zarr-3 style group: create_array(name, shape=, dtype=) instead of create_dataset."""
+
+    def __init__(self):
+        super().__init__()
+        self.attrs = {}
+
+    def create_array(self, name, shape=None, dtype=None):
+        self[name] = FakeH5Dataset(shape, dtype)
+        return self[name]

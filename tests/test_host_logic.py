@@ -228,3 +228,18 @@ def test_hdf5_v1_layout_roundtrip(oracle):
     g.attrs["flacarray_format_version"] = "0"
     with pytest.raises(RuntimeError):
         H.read_compressed(g)
+
+
+def test_zarr_v1_layout_roundtrip(oracle):
+    """The Zarr layout is the HDF5 one; zarr-3 groups create arrays with create_array (zarr.py:236-241)."""
+    from flacarray_amd import zarr as Z
+    from tests.conftest import FakeZarr3Group, sinusoid_noise_i32
+
+    x = sinusoid_noise_i32(4, 3000, seed=8)
+    blob, st, nb = oracle.encode_i32(x, 5)
+    g = FakeZarr3Group()
+    Z.write_compressed(g, (4,), (4,), 3000, st, st, nb, None, None, blob, 1)
+    assert set(g) == {"stream_starts", "stream_bytes", "compressed"} and g.attrs["flacarray_format_version"] == "1"
+    ls, gs, comp, nch, s2, n2, o2, g2, dist, idx = Z.read_compressed(g)
+    assert ls == (4, 3000) and o2 is None and g2 is None
+    assert np.array_equal(oracle.decode_i32(comp, s2, n2, 3000), x)
