@@ -598,12 +598,15 @@ __device__ __forceinline__ void ring_window(const uint32_t* ring, uint32_t bitpo
 
 struct BitsRet {
     uint32_t val, bitpos, next_chunk;
+    uint32_t bad;  // a unary run longer than any sane code: corrupt or truncated stream
 };
+constexpr uint32_t kUnaryLimit = 1u << 20;
 // read n (0..32) bits
 __device__ __noinline__ BitsRet slow_get(const uint8_t* cbase, const uint8_t* lim16, uint32_t* ring, uint32_t bitpos,
                                          uint32_t next_chunk, int n) {
     BitsRet r;
     r.val = 0;
+    r.bad = 0;
     if (n > 0) {
         while (((bitpos + 64) >> kChunkShift) >= next_chunk) { ring_load_chunk(cbase, lim16, ring, next_chunk); next_chunk++; }
         uint32_t A, B;
@@ -632,8 +635,9 @@ __device__ __noinline__ BitsRet slow_unary(const uint8_t* cbase, const uint8_t* 
         }
         q += 32;
         bitpos += 32;
-        if (q > (1u << 24)) break;  // corrupt stream guard: every lane reaches an exit
+        if (q > kUnaryLimit) break;  // corrupt stream guard: every lane reaches an exit
     }
+    r.bad = (q > kUnaryLimit) ? 1u : 0u;
     r.val = q;
     r.bitpos = bitpos;
     r.next_chunk = next_chunk;
@@ -676,6 +680,7 @@ __device__ __noinline__ BitsRet slow_sample(const uint8_t* cbase, const uint8_t*
         r = slow_get(cbase, lim16, ring, q.bitpos, q.next_chunk, k);
         const uint32_t uu = (q.val << k) | r.val;
         r.val = (uint32_t)((int32_t)(uu >> 1) ^ -(int32_t)(uu & 1));
+        r.bad = q.bad;
     }
     r.next_chunk = ring_ensure(cbase, lim16, ring, r.bitpos, r.next_chunk);
     return r;
@@ -683,7 +688,7 @@ __device__ __noinline__ BitsRet slow_sample(const uint8_t* cbase, const uint8_t*
 
 #define FA_GET(n) ({ const BitsRet r_ = slow_get(cbase, lim16, ring, bitpos, next_chunk, (n)); bitpos = r_.bitpos; next_chunk = r_.next_chunk; r_.val; })
 #define FA_GETS(n) ({ const int n_ = (n); const uint32_t v_ = FA_GET(n_); (n_ == 0) ? 0 : ((int32_t)(v_ << (32 - n_)) >> (32 - n_)); })
-#define FA_UNARY() ({ const BitsRet r_ = slow_unary(cbase, lim16, ring, bitpos, next_chunk); bitpos = r_.bitpos; next_chunk = r_.next_chunk; r_.val; })
+#define FA_UNARY() ({ const BitsRet r_ = slow_unary(cbase, lim16, ring, bitpos, next_chunk); bitpos = r_.bitpos; next_chunk = r_.next_chunk; if (r_.bad) bad = true; r_.val; })
 
 // MO = history depth of this variant (8, 16 or 32).  Tasks whose predictor order exceeds MO are
 // left for a later pass (flag word); tasks with order <= MO_DONE were done by an earlier one.
@@ -1037,6 +1042,10 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
                         r = (int32_t)sr.val;
                         nbp = sr.bitpos;
                         next_chunk = sr.next_chunk;
+                        if (sr.bad) {  // stop consuming: the rest of this lane's frame is zero-width
+                            atomicOr(a.err, kErrDecodeProcess);
+                            escw = 0; kf = 64; pleft = 0x7fffffff; r = 0; nbp = bitpos;
+                        }
                     }
                 }
             }

@@ -755,6 +755,7 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                     int* meta = reinterpret_cast<int*>(scr + 220);             // usable order
                     if (lane == 0) meta[0] = levinson<MLO>(autoc, mlo, coef, err);
                     lds_fence();
+                    FA_STAMP(13);
                     const int usable = meta[0];
                     int prec = a.precision;
                     // order choice: lane o evaluates order o+1 (expected bits from the residual energy),
@@ -785,6 +786,7 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                         }
                         lo = bi + 1;
                     }
+                    FA_STAMP(14);
                     if (bps <= 17) {
                         const int limp = 32 - bps - ilog2_u64((uint64_t)lo);
                         if (prec > limp) prec = limp;

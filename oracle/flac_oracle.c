@@ -964,7 +964,9 @@ static int decode_frame(const uint8_t *s, int64_t nbytes, int64_t *off, int si_b
 static int decode_stream(const uint8_t *s, int64_t nbytes, int nch, int64_t stream_size, int64_t first, int64_t n_decode, int32_t *out) {
     if (nbytes < 42 || memcmp(s, "fLaC", 4) != 0) return ERROR_DECODE_INIT;
     int64_t off = 4;
-    int si_bps = 0, si_ch = 0;
+    int si_bps = 0, si_ch = 0, si_bs = 0;
+    const uint8_t *seek = NULL;
+    int64_t npoints = 0;
     while (1) {
         if (off + 4 > nbytes) return ERROR_DECODE_INIT;
         int last = s[off] >> 7, type = s[off] & 0x7f;
@@ -972,15 +974,28 @@ static int decode_stream(const uint8_t *s, int64_t nbytes, int nch, int64_t stre
         off += 4;
         if (off + len > nbytes) return ERROR_DECODE_INIT;
         if (type == 0 && len >= 34) {
+            si_bs = (s[off] == s[off + 2] && s[off + 1] == s[off + 3]) ? ((s[off + 2] << 8) | s[off + 3]) : 0;
             si_ch = ((s[off + 12] >> 1) & 7) + 1;
             si_bps = (((s[off + 12] & 1) << 4) | (s[off + 13] >> 4)) + 1;
         }
+        if (type == 3) { seek = s + off; npoints = len / 18; }
         off += len;
         if (last) break;
     }
     if (si_ch != nch) return ERROR_DECODE_INIT;
     static __thread int32_t frame[2 * 65536];
     int64_t done = 0; /* samples seen */
+    /* seek (what libFLAC's seek_absolute does for the reference, decompress.c:283): use the seek
+     * point of the frame that holds `first` when the table has one */
+    if (seek && si_bs > 0 && first >= si_bs) {
+        int64_t f0 = first / si_bs;
+        if (f0 < npoints) {
+            const uint8_t *p = seek + 18 * f0;
+            uint64_t sn = 0, so = 0;
+            for (int i = 0; i < 8; ++i) { sn = (sn << 8) | p[i]; so = (so << 8) | p[8 + i]; }
+            if (sn == (uint64_t)f0 * (uint64_t)si_bs && off + (int64_t)so < nbytes) { off += (int64_t)so; done = f0 * si_bs; }
+        }
+    }
     while (done < first + n_decode) {
         if (off >= nbytes) return ERROR_DECODE_PROCESS;
         int bs = decode_frame(s, nbytes, &off, si_bps, nch, frame);

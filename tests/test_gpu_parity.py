@@ -524,3 +524,51 @@ def test_read_slices_batched_int64(fa):
     got = fl.read_slices(streams, first, count)
     for s_, f_, c_, g_ in zip(streams, first, count, got):
         assert g_.dtype == np.int64 and np.array_equal(g_, x[s_, f_ : f_ + c_])
+
+
+@pytest.mark.parametrize("stereo", [False, True])
+def test_corrupted_and_truncated_streams_terminate(fa, oracle, stereo):
+    """Damaged input must come back quickly, as an error or as (wrong) samples: zeroed regions, random
+    byte flips inside frames, streams cut short, with and without a seek table.  Every reader loop has
+    an exit (a unary run longer than 2^20 bits kills the lane's frame)."""
+    import time
+
+    import torch
+
+    from tests.conftest import strip_seektable
+
+    rng = np.random.default_rng(123)
+    n = 5 * 4096 + 100
+    if stereo:
+        x = (np.cumsum(rng.integers(-(2**33), 2**33, (3, n)), axis=1)).astype(np.int64)
+        blob, st, nb = oracle.encode_i64(x, 5)
+    else:
+        x = sinusoid_noise_i32(3, n, seed=9)
+        blob, st, nb = oracle.encode_i32(x, 5)
+    dev = torch.device("cuda", 0)
+    variants = []
+    for seed in range(4):
+        r = np.random.default_rng(seed)
+        b = blob.copy()
+        lo = int(st[1]) + 300
+        for _ in range(20):
+            b[r.integers(lo, int(st[1] + nb[1]) - 2)] ^= np.uint8(r.integers(1, 256))
+        variants.append((b, st, nb))
+    z = blob.copy()
+    z[int(st[0]) + 500 : int(st[0]) + 9000] = 0  # a zeroed region: endless unary runs
+    variants.append((z, st, nb))
+    variants.append((blob, st, np.array([nb[0], nb[1] // 2, nb[2]], dtype=np.int64)))  # stream 1 cut short
+    variants += [strip_seektable(*v) for v in variants[:2]] + [strip_seektable(z, st, nb)]
+    t0 = time.perf_counter()
+    for b, s_, n_ in variants:
+        tb, ts, tn = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (b, s_, n_))
+        try:
+            y = fa.decode_flac_device(tb, ts, tn, n, is_int64=stereo).cpu().numpy()
+            assert y.shape == x.shape
+        except RuntimeError as e:
+            assert "Decoding failed" in str(e)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 20.0
+    # the intact streams still decode afterwards
+    tb, ts, tn = (torch.from_numpy(a).to(dev) for a in (blob, st, nb))
+    assert np.array_equal(fa.decode_flac_device(tb, ts, tn, n, is_int64=stereo).cpu().numpy(), x)

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--channels", type=int, default=4096)
     ap.add_argument("--samples", type=int, default=1 << 20)
     ap.add_argument("--slices", type=int, default=10000)
+    ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
     import torch
 
@@ -80,6 +81,27 @@ def main():
         good = good and bool(torch.equal(res[off[i] : off[i] + cnt[i]], x[ch[i], first[i] : first[i] + cnt[i]]))
     out["cfg5_slices"] = {"slices": ns, "seconds": round(dt, 4), "slices_per_s": round(ns / dt, 1),
                           "Msamples_per_s": round(cnt.sum() / dt / 1e6, 1), "verified": good}
+    # CPU side of cfg 5: the same requests as single-stream decode calls at the C level of the
+    # CPU oracle (a port; it seeks through the SEEKTABLE as libFLAC's seek_absolute would), on a subset
+    # of the streams copied to the host; scaled to the request count
+    if not args.no_cpu:
+        from oracle import oracle as O
+
+        O.lib().oracle_set_threads(1)
+        n_host = 64
+        hb_st, hb_nb = st[:n_host].cpu().numpy(), nb[:n_host].cpu().numpy()
+        hb = comp[: int(hb_st[-1] + hb_nb[-1])].cpu().numpy()
+        xs = x[:n_host].cpu().numpy()
+        m = min(ns, 1000)
+        t0 = time.perf_counter()
+        okc = True
+        for i in range(m):
+            c = int(ch[i]) % n_host
+            y = O.decode_i32(hb, hb_st[c : c + 1], hb_nb[c : c + 1], n, int(first[i]), int(first[i] + cnt[i]))
+            okc = okc and bool(np.array_equal(y[0], xs[c, first[i] : first[i] + cnt[i]]))
+        dtc = time.perf_counter() - t0
+        out["cfg5_slices"]["cpu_port_1thread"] = {"slices": m, "seconds": round(dtc, 3), "slices_per_s": round(m / dtc, 1),
+                                                   "verified": okc, "through": "ctypes call per slice"}
     print(json.dumps(out))
 
 

@@ -13,7 +13,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 PHASES = ["P0 load/wasted", "P2 fixed loop", "P2 reduce", "P2 rice search", "P3 autocorr loop", "P3 butterfly", "P3 levinson+quant",
-          "P4 lpc residual", "P4 rice search", "emit prep", "preamble", "rows", "tail"]
+          "P4 lpc residual", "P4 rice search", "emit prep", "preamble", "rows", "tail", "(6a) levinson", "(6b) order choice"]
 
 
 def main():
