@@ -32,7 +32,9 @@ using namespace fa;
         }                                                                                         \
     } while (0)
 
-std::mutex g_mu;
+std::mutex g_mu;            // device-state caches (windows, CRC table, scratch slots)
+std::recursive_mutex g_api_mu;  // one compute call at a time: the calls share the cached scratch buffers
+#define FA_API_LOCK std::lock_guard<std::recursive_mutex> api_lock_(g_api_mu)
 
 // optional in-library kernel timing (HIP events on the launch stream), see fa_profile_enable
 bool g_prof = false;
@@ -424,6 +426,7 @@ int64_t fa_encode_workspace_bytes_i64(int64_t n_stream, int64_t stream_size, uin
 static int encode_device_begin(const int32_t* d_data, int nch, int64_t n_stream, int64_t stream_size, uint32_t level,
                                void* d_workspace, int64_t workspace_bytes, int64_t* d_starts, int64_t* d_nbytes,
                                int64_t* h_total_bytes, int32_t* d_info, void* stream) {
+    FA_API_LOCK;
     EncodePlan pl;
     int rc = make_plan(n_stream, stream_size, level, &pl, nch);
     if (rc) return rc;
@@ -498,6 +501,7 @@ int fa_encode_i64_device_begin(const int64_t* d_data, int64_t n_stream, int64_t 
 
 static int encode_device_finish(int nch, int64_t n_stream, int64_t stream_size, uint32_t level, void* d_workspace,
                                 const int64_t* d_starts, unsigned char* d_bytes, void* stream) {
+    FA_API_LOCK;
     EncodePlan pl;
     int rc = make_plan(n_stream, stream_size, level, &pl, nch);
     if (rc) return rc;
@@ -535,6 +539,7 @@ int fa_decode_i32_device(const unsigned char* d_bytes, int64_t n_bytes, const in
                          const int64_t* d_nbytes, int64_t n_stream, int64_t stream_size, int64_t first_sample,
                          int64_t last_sample, int32_t* d_out_i32, float* d_out_f32, const float* d_offsets,
                          const float* d_gains, void* stream) {
+    FA_API_LOCK;
     if (n_stream <= 0) return FA_ERROR_ZERO_NSTREAM;
     if (stream_size <= 0) return FA_ERROR_DECODE_STREAMSIZE;
     if ((d_out_i32 == nullptr) == (d_out_f32 == nullptr)) return FA_ERROR_CONVERT_TYPE;
@@ -552,6 +557,7 @@ int fa_decode_slices_i32_device(const unsigned char* d_bytes, int64_t n_bytes, c
                                 const int64_t* slice_stream, const int64_t* slice_first, const int64_t* slice_count,
                                 const int64_t* out_offset, int32_t* d_out_i32, float* d_out_f32,
                                 const float* d_offsets, const float* d_gains, void* stream) {
+    FA_API_LOCK;
     if (n_stream <= 0) return FA_ERROR_ZERO_NSTREAM;
     if (stream_size <= 0) return FA_ERROR_DECODE_STREAMSIZE;
     if (n_slices <= 0) return FA_ERROR_NONE;
@@ -566,6 +572,7 @@ int fa_decode_i64_device(const unsigned char* d_bytes, int64_t n_bytes, const in
                          const int64_t* d_nbytes, int64_t n_stream, int64_t stream_size, int64_t first_sample,
                          int64_t last_sample, int64_t* d_out_i64, double* d_out_f64, const double* d_offsets,
                          const double* d_gains, void* stream) {
+    FA_API_LOCK;
     if (n_stream <= 0) return FA_ERROR_ZERO_NSTREAM;
     if (stream_size <= 0) return FA_ERROR_DECODE_STREAMSIZE;
     if ((d_out_i64 == nullptr) == (d_out_f64 == nullptr)) return FA_ERROR_CONVERT_TYPE;
@@ -583,6 +590,7 @@ int fa_decode_slices_i64_device(const unsigned char* d_bytes, int64_t n_bytes, c
                                 const int64_t* slice_stream, const int64_t* slice_first, const int64_t* slice_count,
                                 const int64_t* out_offset, int64_t* d_out_i64, double* d_out_f64,
                                 const double* d_offsets, const double* d_gains, void* stream) {
+    FA_API_LOCK;
     if (n_stream <= 0) return FA_ERROR_ZERO_NSTREAM;
     if (stream_size <= 0) return FA_ERROR_DECODE_STREAMSIZE;
     if (n_slices <= 0) return FA_ERROR_NONE;
@@ -595,6 +603,7 @@ int fa_decode_slices_i64_device(const unsigned char* d_bytes, int64_t n_bytes, c
 
 int fa_float32_to_int32_device(const float* d_input, int64_t n_stream, int64_t stream_size, const float* d_quanta,
                                int32_t* d_output, float* d_offsets, float* d_gains, void* stream) {
+    FA_API_LOCK;
     if (n_stream <= 0) return FA_ERROR_ZERO_NSTREAM;
     if (stream_size <= 0) return FA_ERROR_ZERO_STREAMSIZE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -614,6 +623,7 @@ int fa_float32_to_int32_device(const float* d_input, int64_t n_stream, int64_t s
 
 int fa_int32_to_float32_device(const int32_t* d_input, int64_t n_stream, int64_t stream_size, const float* d_offsets,
                                const float* d_gains, float* d_output, void* stream) {
+    FA_API_LOCK;
     if (n_stream <= 0 || stream_size <= 0) return FA_ERROR_NONE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int64_t cps = (stream_size + kDequantChunk - 1) / kDequantChunk;
@@ -625,6 +635,7 @@ int fa_int32_to_float32_device(const int32_t* d_input, int64_t n_stream, int64_t
 
 int fa_float64_to_int64_device(const double* d_input, int64_t n_stream, int64_t stream_size, const double* d_quanta,
                                int64_t* d_output, double* d_offsets, double* d_gains, void* stream) {
+    FA_API_LOCK;
     if (n_stream <= 0) return FA_ERROR_ZERO_NSTREAM;
     if (stream_size <= 0) return FA_ERROR_ZERO_STREAMSIZE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -644,6 +655,7 @@ int fa_float64_to_int64_device(const double* d_input, int64_t n_stream, int64_t 
 
 int fa_int64_to_float64_device(const int64_t* d_input, int64_t n_stream, int64_t stream_size, const double* d_offsets,
                                const double* d_gains, double* d_output, void* stream) {
+    FA_API_LOCK;
     if (n_stream <= 0 || stream_size <= 0) return FA_ERROR_NONE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int64_t cps = (stream_size + kDequantChunk - 1) / kDequantChunk;
@@ -659,6 +671,7 @@ int fa_int64_to_float64_device(const int64_t* d_input, int64_t n_stream, int64_t
 // ---------------------------------------------------------------------------------------------
 static int encode_host(const int32_t* data, int nch, int64_t n_stream, int64_t stream_size, uint32_t level, int64_t* n_bytes,
                        int64_t* starts, unsigned char** bytes) {
+    FA_API_LOCK;
     if (level > 8) return FA_ERROR_INVALID_LEVEL;        // compress.c:144-146
     if (n_stream == 0) return FA_ERROR_ZERO_NSTREAM;     // compress.c:147-149
     if (stream_size == 0) return FA_ERROR_ZERO_STREAMSIZE;  // compress.c:150-152
@@ -749,6 +762,7 @@ int encode_i64_threaded(int64_t* const data, int64_t n_stream, int64_t stream_si
 
 static int decode_host(const unsigned char* bytes, const int64_t* starts, const int64_t* nbytes, int64_t n_stream,
                        int64_t stream_size, int64_t first_sample, int64_t last_sample, void* data_v, int nch) {
+    FA_API_LOCK;
     const size_t esz = 4 * (size_t)nch;  // bytes per decoded sample
     unsigned char* data = reinterpret_cast<unsigned char*>(data_v);
     int64_t first_decode, n_decode;
@@ -811,6 +825,7 @@ int decode_i64(unsigned char* const bytes, int64_t* const starts, int64_t* const
 
 int float32_to_int32(float const* input, int64_t n_stream, int64_t stream_size, float const* quanta, int32_t* output,
                      float* offsets, float* gains) {
+    FA_API_LOCK;
     if (n_stream <= 0 || stream_size <= 0) return FA_ERROR_NONE;
     if (fa_device_count() <= 0) return FA_ERROR_DEVICE;
     size_t free_b = 0, total_b = 0;
@@ -843,6 +858,7 @@ int float32_to_int32(float const* input, int64_t n_stream, int64_t stream_size, 
 
 void int32_to_float32(int32_t const* input, int64_t n_stream, int64_t stream_size, float const* offsets,
                       float const* gains, float* output) {
+    FA_API_LOCK;
     if (n_stream <= 0 || stream_size <= 0) return;
     if (fa_device_count() <= 0) {
         std::fprintf(stderr, "flacarray_hip: int32_to_float32 called without a HIP device\n");
@@ -875,6 +891,7 @@ void int32_to_float32(int32_t const* input, int64_t n_stream, int64_t stream_siz
 
 int float64_to_int64(double const* input, int64_t n_stream, int64_t stream_size, double const* quanta, int64_t* output,
                      double* offsets, double* gains) {
+    FA_API_LOCK;
     if (n_stream <= 0 || stream_size <= 0) return FA_ERROR_NONE;
     if (fa_device_count() <= 0) return FA_ERROR_DEVICE;
     size_t free_b = 0, total_b = 0;
@@ -907,6 +924,7 @@ int float64_to_int64(double const* input, int64_t n_stream, int64_t stream_size,
 
 void int64_to_float64(int64_t const* input, int64_t n_stream, int64_t stream_size, double const* offsets,
                       double const* gains, double* output) {
+    FA_API_LOCK;
     if (n_stream <= 0 || stream_size <= 0) return;
     if (fa_device_count() <= 0) {
         std::fprintf(stderr, "flacarray_hip: int64_to_float64 called without a HIP device\n");

@@ -572,3 +572,32 @@ def test_corrupted_and_truncated_streams_terminate(fa, oracle, stereo):
     # the intact streams still decode afterwards
     tb, ts, tn = (torch.from_numpy(a).to(dev) for a in (blob, st, nb))
     assert np.array_equal(fa.decode_flac_device(tb, ts, tn, n, is_int64=stereo).cpu().numpy(), x)
+
+
+def test_concurrent_host_calls(fa, oracle):
+    """The reference's entry points are re-entrant (compress.c has no globals).  Here calls
+    share cached device scratch, so the library serialises them: concurrent callers get correct results."""
+    import threading
+
+    xs = [sinusoid_noise_i32(3, 20000 + 1000 * i, seed=40 + i) for i in range(4)]
+    want = [oracle.encode_i32(x, 5)[0] for x in xs]
+    got, errs = [None] * 4, []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                c, s, n = fa.encode_flac(xs[i], 5)
+                y = fa.decode_flac(np.asarray(c), s, n, xs[i].shape[1])
+                assert np.array_equal(y, xs[i])
+            got[i] = np.asarray(c).copy()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
