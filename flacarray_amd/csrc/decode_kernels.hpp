@@ -703,11 +703,6 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
     static_assert(NCH == 1 || (kTileW == 32 && !F32), "two-channel variant: 32-sample tiles, integer output");
     __shared__ __attribute__((aligned(16))) uint32_t rings[kDecRingWords * kLaneStride];
     __shared__ __attribute__((aligned(16))) int32_t tile[kTileW * kLaneStride];  // sample t of lane l at t*64 + (l ^ 8*(t>>2))
-#ifdef FA_DEC_LDS_PAD
-    __shared__ int32_t lds_pad_[FA_DEC_LDS_PAD];  // occupancy experiment
-    if (a.n_tasks == -12345) lds_pad_[threadIdx.x] = (int32_t)a.nf;
-    if (a.n_tasks == -12346) a.err[0] = lds_pad_[threadIdx.x + 1];
-#endif
     __shared__ int64_t row_out[64];
     __shared__ int2 row_rng[64];
     __shared__ float2 row_fg[F32 ? 64 : 1];
@@ -1079,7 +1074,6 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
             hbw = 0;
         }
         constexpr int kRowsPerPass = 64 / kTileG;
-#ifndef FA_NO_FASTFLUSH
         if (!F32 && all_al && tbase >= lo_max && tbase + kTileW <= hi_min) {
 #pragma unroll
             for (int it = 0; it < kTileG; ++it) {
@@ -1094,7 +1088,6 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
             __builtin_amdgcn_wave_barrier();
             return;
         }
-#endif
 #pragma unroll 4
         for (int it = 0; it < kTileG; ++it) {
             const int r = it * kRowsPerPass + (lane / kTileG);
