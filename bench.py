@@ -238,7 +238,7 @@ def main():
         }
         if gather_s is not None:
             out["allgatherv_s"] = round(gather_s, 4)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(n_samp)
         print(json.dumps(out))
     if world > 1:
