@@ -601,3 +601,50 @@ def test_concurrent_host_calls(fa, oracle):
     assert not errs, errs
     for g, w in zip(got, want):
         assert np.array_equal(g, w)
+
+
+def _reference_fake_data(shape, sigma, dtype, seed=123456789):
+    """create_fake_data of the reference (demo.py:12-110) without MPI: uniform full-range integers with
+    the extremes at positions 0 / 1 when sigma is None, else the sinusoid + noise field."""
+    rng = np.random.default_rng(seed)
+    n = int(np.prod(shape))
+    if sigma is None:
+        lo, hi = np.iinfo(dtype).min, np.iinfo(dtype).max
+        flat = rng.integers(low=lo, high=hi, size=n, dtype=np.int64).astype(dtype)
+        flat[0], flat[1] = lo, hi
+        return flat.reshape(shape)
+    lead = shape[:-1] + (1,)
+    ss = shape[-1]
+    t = np.arange(ss)
+    minf = 5 / ss
+    wave = np.zeros(ss, dtype=dtype)
+    for freq, amp in zip([3 * minf, minf], [2 * sigma, 6 * sigma]):
+        wave[:] += amp * np.sin(2 * np.pi * freq * t)
+    scale = rng.random(size=lead)
+    data = np.empty(shape, dtype=dtype)
+    data[...] = scale * wave if len(shape) > 1 else (scale * wave).reshape(shape)
+    data[...] += rng.normal(0.0, sigma, n).reshape(shape)
+    return data
+
+
+@pytest.mark.parametrize("shape", [(4, 3, 1000), (10000,)])
+@pytest.mark.parametrize("dt,sigma,quant", [(np.int32, None, None), (np.int64, None, None), (np.float32, 1.0, 1.0e-6), (np.float64, 1.0, 1.0e-7)])
+def test_reference_helpers_recipe(fa, shape, dt, sigma, quant):
+    """tests/array.py:26-146 (test_helpers) as written there: every dtype, both shapes, full decode and
+    the 10-sample slice around the middle; ints exact, floats within 10 quanta."""
+    dt = np.dtype(dt)
+    x = _reference_fake_data(shape, sigma, dt)
+    is64 = dt in (np.dtype(np.int64), np.dtype(np.float64))
+    ftol = 1.0e-5 if quant is None else 10.0 * quant
+    first, last = shape[-1] // 2 - 5, shape[-1] // 2 + 5
+    comp, starts, nbytes, off, gain = fa.array_compress(x, level=5, quanta=quant)
+    if quant is None:
+        assert off is None and gain is None
+    full = fa.array_decompress(comp, shape[-1], starts, nbytes, stream_offsets=off, stream_gains=gain, is_int64=is64)
+    part = fa.array_decompress(comp, shape[-1], starts, nbytes, stream_offsets=off, stream_gains=gain,
+                               first_stream_sample=first, last_stream_sample=last, is_int64=is64)
+    assert full.dtype == dt and full.shape == x.shape and part.shape == x[..., first:last].shape
+    if quant is None:
+        assert np.array_equal(full, x) and np.array_equal(part, x[..., first:last])
+    else:
+        assert np.allclose(full, x, atol=ftol) and np.allclose(part, x[..., first:last], atol=ftol)
