@@ -50,7 +50,10 @@ class FlacArray:
             self._mpi_comm = other._mpi_comm
         else:
             self._shape = tuple(shape)
-            self._global_shape = tuple(global_shape) if global_shape is not None else tuple(shape)
+            if global_shape is not None:
+                self._global_shape = tuple(global_shape)
+            else:  # single process: mpi.py:109-117 (a 1-D array is one stream: global shape (1, n))
+                self._global_shape = (1, self._shape[0]) if len(self._shape) == 1 else self._shape
             self._compressed = compressed
             self._dtype = np.dtype(dtype)
             self._stream_starts = stream_starts
@@ -364,7 +367,7 @@ class FlacArray:
         return FlacArray(
             None,
             shape=arr.shape,
-            global_shape=arr.shape,
+            global_shape=(1, arr.shape[0]) if arr.ndim == 1 else arr.shape,  # global_array_properties, mpi.py:109-117
             compressed=compressed,
             dtype=arr.dtype,
             stream_starts=starts,
@@ -411,7 +414,7 @@ class FlacArray:
         return FlacArray(
             None,
             shape=shape,
-            global_shape=shape if keep is not None else global_shape,
+            global_shape=global_shape,
             compressed=compressed,
             dtype=dt,
             stream_starts=stream_starts,

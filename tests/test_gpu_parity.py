@@ -648,3 +648,47 @@ def test_reference_helpers_recipe(fa, shape, dt, sigma, quant):
         assert np.array_equal(full, x) and np.array_equal(part, x[..., first:last])
     else:
         assert np.allclose(full, x, atol=ftol) and np.allclose(part, x[..., first:last], atol=ftol)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_reference_float_conversion_recipes(fa, dt):
+    """tests/utils.py:22-108 (test_float64 / test_float32): float_to_int -> int_to_float with a scalar
+    quanta, a scalar and a per-stream precision, and a per-stream quanta array."""
+    shape = (4, 3, 1000)
+    data = _reference_fake_data(shape, 1.0, np.dtype(np.float64)).astype(dt)
+    if dt == np.float64:
+        i, o, g = fa.float_to_int(data, quanta=1.0e-16, precision=None)
+        assert i.dtype == np.int64 and np.allclose(fa.int_to_float(i, o, g), data, rtol=1e-15, atol=1e-15)
+    else:
+        i, o, g = fa.float_to_int(data, quanta=1e-6, precision=None)
+        assert i.dtype == np.int32 and np.allclose(fa.int_to_float(i, o, g), data, rtol=1e-5, atol=1e-5)
+    for kw in (dict(quanta=None, precision=5), dict(quanta=None, precision=5 * np.ones(shape[:-1])),
+               dict(quanta=1e-5, precision=None), dict(quanta=1e-5 * np.ones(shape[:-1]), precision=None)):
+        i, o, g = fa.float_to_int(data, **kw)
+        assert o.shape == shape[:-1] and g.shape == shape[:-1]
+        assert np.allclose(fa.int_to_float(i, o, g), data, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("group_kind", ["h5", "zarr3"])
+@pytest.mark.parametrize("shape", [(4, 3, 1000), (10000,)])
+def test_reference_io_recipes(fa, group_kind, shape):
+    """tests/hdf5.py:29-160 and tests/zarr.py:28-160: write_array / read_array and FlacArray.write_* /
+    read_* for every dtype (ints exact, floats atol 1e-6), on in-memory stand-ins for the group objects."""
+    from flacarray_amd import hdf5 as H
+    from flacarray_amd import zarr as Z
+    from tests.conftest import FakeH5Group, FakeZarr3Group
+
+    mod, new = (H, FakeH5Group) if group_kind == "h5" else (Z, FakeZarr3Group)
+    for dt, sigma, quant in [(np.int32, None, None), (np.int64, None, None), (np.float32, 1.0, 1.0e-7), (np.float64, 1.0, 1.0e-15)]:
+        dt = np.dtype(dt)
+        x = _reference_fake_data(shape, sigma, dt)
+        g = new()
+        mod.write_array(x, g, level=5, quanta=quant, precision=None, mpi_comm=None, use_threads=True)
+        check = mod.read_array(g, keep=None, stream_slice=None, keep_indices=False, use_threads=True)
+        assert check.dtype == dt and check.shape == x.shape
+        assert np.array_equal(check, x) if quant is None else np.allclose(check, x, atol=1e-6)
+        fl = fa.FlacArray.from_array(x, quanta=quant, use_threads=True)
+        g2 = new()
+        (fl.write_hdf5 if group_kind == "h5" else fl.write_zarr)(g2)
+        back = (fa.FlacArray.read_hdf5 if group_kind == "h5" else fa.FlacArray.read_zarr)(g2)
+        assert back == fl
