@@ -167,8 +167,24 @@ def _check_array_surface():
     for key in keys:
         assert f[key].shape == x[key].shape, key
         assert np.array_equal(f[key], x[key]), key
+    # the reference's own key list (tests/array.py:181-194), shapes AND values
+    for key in [
+        (slice(0)), (slice(1, 3)), (slice(3, 1)), (slice(3, 1, -1)), (1, 2, 5, 50), (1, 2, 5),
+        (2, slice(0, 1, 1), slice(0, 1, 1), slice(None)), (1, slice(1, 3, 1), slice(6, 8, 1), 50),
+        (slice(1, 3, 1), 2, slice(6, 8, 1), slice(60, 80, 1)), (2, 1, slice(2, 8, 2), slice(80, 120, 1)),
+        (2, 1, slice(2, 8, 2), slice(80, None)), (2, 1, slice(2, 8, 2), slice(None, 10)),
+    ]:
+        assert np.shape(f[key]) == np.shape(x[key]), key
+        if key == slice(3, 1, -1):
+            # streams are selected through a keep mask (array.py:339-378), so a negative leading step
+            # keeps the ascending order: the reference pins only the shape here
+            assert np.array_equal(f[key], x[2:4]), key
+        else:
+            assert np.array_equal(f[key], x[key]), key
     x1 = sinusoid_noise_i32(1, 10000, seed=9)[0]
     f1 = fa.FlacArray.from_array(x1)
+    for key in [(slice(0)), (slice(1, 3)), (100,)]:  # tests/array.py:219
+        assert np.shape(f1[key]) == np.shape(x1[key]) and np.array_equal(f1[key], x1[key]), key
     for key in (slice(None), slice(100, 200), 77):
         assert np.array_equal(f1[key], x1[key]) and np.shape(f1[key]) == np.shape(x1[key])
     # to_array with keep mask + indices (array.py:518-584)
