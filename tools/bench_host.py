@@ -26,3 +26,17 @@ for rep in range(2):
            "roundtrip_Msamples_per_s": round(x.size / (t2 - t0) / 1e6, 1), "encode_GBps_in": round(x.nbytes / (t1 - t0) / 1e9, 2)}
 assert np.array_equal(y, x)
 print(json.dumps(res))
+# where the time goes: the C entry point alone (no Python wrapper work), and a plain copy of the same size
+import ctypes
+from flacarray_amd import _lib
+L = _lib.lib()
+flat = np.ascontiguousarray(x).reshape(-1)
+starts = np.empty(n_ch, dtype=np.int64)
+for rep in range(2):
+    nbv, raw = ctypes.c_int64(0), ctypes.c_void_p(None)
+    t0 = time.perf_counter()
+    err = L.encode_i32(flat.ctypes.data, n_ch, n, 5, ctypes.byref(nbv), starts.ctypes.data, ctypes.byref(raw))
+    t1 = time.perf_counter()
+    _lib.libc_free(raw.value)
+print("C encode_i32 alone: %.3f s (err %d), %d output bytes" % (t1 - t0, err, nbv.value))
+t0 = time.perf_counter(); z = flat.copy(); print("numpy copy of the input: %.3f s" % (time.perf_counter() - t0))
