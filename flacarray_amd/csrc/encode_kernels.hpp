@@ -195,6 +195,15 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
     return v;
 }
 
+// |a - b| + c on unsigned operands in ONE instruction.  The generic __usad is rewritten by the
+// optimiser into min / max / subtract / add (four instructions) when its operands are sign-biased
+// values, which is exactly how the fixed-predictor loop uses it.
+__device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // OR the low n bits (1..32) of v into the circular bit buffer at absolute bit position pos
 __device__ __forceinline__ void ring_put(uint32_t* ring, uint32_t pos, uint32_t v, int n) {
     uint32_t w = pos >> 5;
@@ -579,11 +588,11 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                     const int x = xs[e];
                     const int e1 = x - p1, e2 = e1 - pe1, e3 = e2 - pe2;
                     const uint32_t xb = (uint32_t)x ^ BIAS;
-                    const uint32_t n0 = __usad(xb, BIAS, s0);
-                    const uint32_t n1 = __usad(xb, (uint32_t)p1 ^ BIAS, s1);
-                    const uint32_t n2 = __usad((uint32_t)e1 ^ BIAS, (uint32_t)pe1 ^ BIAS, s2);
-                    const uint32_t n3 = __usad((uint32_t)e2 ^ BIAS, (uint32_t)pe2 ^ BIAS, s3);
-                    const uint32_t n4 = __usad((uint32_t)e3 ^ BIAS, (uint32_t)pe3 ^ BIAS, s4);
+                    const uint32_t n0 = sad_u32(xb, BIAS, s0);
+                    const uint32_t n1 = sad_u32(xb, (uint32_t)p1 ^ BIAS, s1);
+                    const uint32_t n2 = sad_u32((uint32_t)e1 ^ BIAS, (uint32_t)pe1 ^ BIAS, s2);
+                    const uint32_t n3 = sad_u32((uint32_t)e2 ^ BIAS, (uint32_t)pe2 ^ BIAS, s3);
+                    const uint32_t n4 = sad_u32((uint32_t)e3 ^ BIAS, (uint32_t)pe3 ^ BIAS, s4);
                     if constexpr (MASK) {
                         const int gi = g0 + 4 * t + e;
                         const bool v = gi < bs;
