@@ -622,6 +622,8 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                     fold();
                 }
             } else {
+                // (short frames: rare, kept rolled so that its compare masks do not inflate the SGPR demand)
+#pragma unroll 1
                 for (int t = 1; t < 16; ++t) {
                     group(std::true_type{}, t);
                     if ((t & 3) == 3) fold();
@@ -638,7 +640,7 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
             double e2b = e1b - ((double)h.y - (double)h.x);
             double pe3 = pe2 - e2b;
             const int g0 = kChunk * lane;
-#pragma unroll 4
+#pragma unroll 1
             for (int t = 0; t < 16; ++t) {
                 int4 xv = *reinterpret_cast<const int4*>(&smp[cbase + 4 * t]);
                 int xs[4] = {xv.x, xv.y, xv.z, xv.w};
@@ -862,7 +864,7 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
 #pragma unroll 4
                                 for (int t = kWarmGroups; t < 16; ++t) group(std::false_type{}, t);
                             } else {
-#pragma unroll 4
+#pragma unroll 1
                                 for (int t = 0; t < 16; ++t) group(std::true_type{}, t);
                             }
                         }
