@@ -327,6 +327,67 @@ __device__ __forceinline__ void rice_search_batch_u32(uint32_t T, int bs, int pr
     }
 }
 
+// The same 32-bit search for partition orders 0..pmax (pmax <= 5) without a single branch and cut into
+// stages, so that the caller can place the stages between groups of independent arithmetic: every
+// stage is a short latency chain (DPP scan, cross-lane gathers, lane reads) that then overlaps the
+// caller's work instead of stalling the wave.  Requires every lane's sum below 2^24.
+struct FastRiceSearch {
+    int bs, pred_order, pmax, lane;
+    uint32_t T, Th, Tl, S, n, pb, SC, best;
+    int M, p, lo_l, k, bpo, kb;
+    bool slot;
+    __device__ __forceinline__ void start(uint32_t tl, int bs_, int pred_order_, int pmax_, int lane_) {
+        bs = bs_; pred_order = pred_order_; pmax = pmax_; lane = lane_;
+        T = wave_incl_scan_u32(tl);
+    }
+    __device__ __forceinline__ void gather() {
+        M = (2 << pmax) - 1;
+        const int Lp = M - lane;
+        slot = (Lp >= 1);
+        const int po = slot ? (31 - __clz(Lp)) : 0;
+        p = lane - (M + 1 - (2 << po));
+        const uint32_t psz = (uint32_t)(bs >> po);
+        const int lpp = (po == 0) ? 64 : (int)(psz / kChunk);
+        int hi_l = (p + 1) * lpp - 1;
+        lo_l = p * lpp - 1;
+        hi_l = hi_l > 63 ? 63 : (hi_l < 0 ? 0 : hi_l);
+        Th = (uint32_t)__builtin_amdgcn_ds_bpermute(hi_l << 2, (int)T);
+        Tl = (uint32_t)__builtin_amdgcn_ds_bpermute((lo_l < 0 ? 0 : (lo_l > 63 ? 63 : lo_l)) << 2, (int)T);
+        n = psz - ((p == 0) ? (uint32_t)pred_order : 0u);
+        n = slot ? n : 1u;
+    }
+    __device__ __forceinline__ void params() {  // rice_param_u32 / rice_part_bits, as selects
+        S = slot ? (Th - ((lo_l >= 0) ? Tl : 0u)) : 0u;
+        const uint32_t fpd = 0x40000u / n;
+        const uint32_t m1 = S - 1;
+        const uint32_t v = (__umulhi(m1, fpd) << 14) | ((m1 * fpd) >> 18);
+        k = (S < 2 || v == 0) ? 0 : (32 - __clz((int)v));
+        const uint32_t rest = (k != 0) ? (S >> ((k - 1) & 31)) : (S << 1);
+        pb = 4u + (uint32_t)(1 + k) * n + rest - (n >> 1);
+        pb = slot ? pb : 0u;
+    }
+    __device__ __forceinline__ void totals() {
+        SC = wave_incl_scan_u32(pb);
+        best = 0xffffffffu;
+        bpo = 0;
+        kb = 0;
+    }
+    // orders are visited from 5 down to 0; strictly smaller wins, the first valid one always does
+    __device__ __forceinline__ void order(int o) {
+        const bool valid = (o <= pmax);
+        const int base = valid ? (M + 1 - (2 << o)) : 0;
+        const int end = valid ? (base + (1 << o) - 1) : 0;
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)SC, end);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)SC, base > 0 ? base - 1 : 0);
+        const uint32_t bits = hi - (base > 0 ? lo : 0u) + 6u;
+        const int kg = __builtin_amdgcn_ds_bpermute(((base + lane) & 63) << 2, k);
+        const bool take = valid && (bits < best);
+        best = take ? bits : best;
+        bpo = take ? o : bpo;
+        kb = take ? kg : kb;
+    }
+};
+
 // full search for a candidate with per-chunk magnitude sums `tl` (exact, as double or u64)
 __device__ __forceinline__ uint64_t rice_search_all(uint64_t tl, int bs, int pred_order, int pmax, int lane, int* best_po,
                                                     int* kbest) {
@@ -687,18 +748,26 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
         }
         FA_STAMP(2);
         int po_fix = 0, k_fix = 0;
-        if (fo >= 0) {
-            const double tl = (fo == 0) ? tot0 : (fo == 1) ? tot1 : (fo == 2) ? tot2 : (fo == 3) ? tot3 : tot4;
-            const int pmax = max_porder_for(bs, a.max_porder, fo);
-            const uint64_t est = 8 + (uint64_t)wasted + (uint64_t)fo * (uint64_t)bps +
-                                 rice_search_all(active ? (uint64_t)tl : 0, bs, fo, pmax, lane, &po_fix, &k_fix);
-            if (est < best_bits) {
-                best_bits = est;
+        const double tl_fix = (fo == 0) ? tot0 : (fo == 1) ? tot1 : (fo == 2) ? tot2 : (fo == 3) ? tot3 : tot4;
+        const int pmax_fix = max_porder_for(bs, a.max_porder, fo < 0 ? 0 : fo);
+        // Full frames with modest sums (the common case): the fixed predictor's partition search is
+        // branch-free and is issued together with the autocorrelation loop below, which hides its
+        // scans, gathers and lane reads.  Otherwise it runs here, on its own.
+        const bool fuse_search = (MLO > 0) && full && fo >= 0 && pmax_fix <= 5 && a.max_lpc_order > 0 && __all(tl_fix < 16777216.0);
+        uint64_t est_fix = 0;
+        auto apply_fixed = [&]() __attribute__((always_inline)) {
+            if (est_fix < best_bits) {
+                best_bits = est_fix;
                 type = 2;
                 order = fo;
                 porder = po_fix;
                 kbest = k_fix;
             }
+        };
+        if (fo >= 0 && !fuse_search) {
+            est_fix = 8 + (uint64_t)wasted + (uint64_t)fo * (uint64_t)bps +
+                      rice_search_all(active ? (uint64_t)tl_fix : 0, bs, fo, pmax_fix, lane, &po_fix, &k_fix);
+            apply_fixed();
             lds_fence();
         }
 
@@ -711,7 +780,46 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                 double acc[MLO + 1];
 #pragma unroll
                 for (int j = 0; j <= MLO; ++j) acc[j] = 0.0;
-                if (active) {
+                if (fuse_search) {
+                    // every lane is active; one basic block: 64 samples of lag products + the search
+                    const int cbase = kChunkStride * (lane + 1);
+                    const int g0 = kChunk * lane;
+                    float4 wv[16];
+                    float wh[MLO];
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) wv[t] = *reinterpret_cast<const float4*>(win + g0 + 4 * t);
+#pragma unroll
+                    for (int j = 0; j < MLO; ++j) wh[j] = (g0 - 1 - j >= 0) ? win[g0 - 1 - j] : 0.0f;
+                    double hist[MLO];
+#pragma unroll
+                    for (int j = 0; j < MLO; ++j) hist[j] = (double)smp[cbase - kChunkStride + 63 - j] * (double)wh[j];
+                    FastRiceSearch fs;
+                    fs.start((uint32_t)tl_fix, bs, fo, pmax_fix, lane);
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        int4 xv = *reinterpret_cast<const int4*>(&smp[cbase + 4 * t]);
+                        const int xs[4] = {xv.x, xv.y, xv.z, xv.w};
+                        const float ws[4] = {wv[t].x, wv[t].y, wv[t].z, wv[t].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const double d = (double)xs[e] * (double)ws[e];
+                            acc[0] = __builtin_fma(d, d, acc[0]);
+#pragma unroll
+                            for (int j = 0; j < MLO; ++j) acc[j + 1] = __builtin_fma(d, hist[j], acc[j + 1]);
+#pragma unroll
+                            for (int j = MLO - 1; j > 0; --j) hist[j] = hist[j - 1];
+                            hist[0] = d;
+                        }
+                        // one stage of the search per group of 4 samples (t is a constant after unrolling)
+                        if (t == 1) fs.gather();
+                        if (t == 3) fs.params();
+                        if (t == 5) fs.totals();
+                        if (t >= 7 && t <= 12) fs.order(12 - t);
+                    }
+                    po_fix = fs.bpo;
+                    k_fix = fs.kb;
+                    est_fix = 8 + (uint64_t)wasted + (uint64_t)fo * (uint64_t)bps + (uint64_t)fs.best;
+                } else if (active) {
                     const int cbase = kChunkStride * (lane + 1);
                     const int g0 = kChunk * lane;
                     // the lane's 64 window values (and the MLO before them) are requested up
@@ -754,6 +862,7 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                     }
                 }
                 FA_STAMP(4);
+                if (fuse_search) apply_fixed();
                 double autoc[MLO + 1];
 #pragma unroll
                 for (int j = 0; j <= MLO; ++j) autoc[j] = wave_sum_butterfly(acc[j]);
