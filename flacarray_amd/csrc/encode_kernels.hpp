@@ -952,12 +952,12 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                                         const bool v = (gi < bs) && (gi >= lo);
                                         const double ar = v ? fa_fabs(r) : 0.0;
                                         tl += ar;
-                                        mxr = ar > mxr ? ar : mxr;
+                                        mxr = __builtin_fmax(mxr, ar);
                                         rs[e] = v ? (int)r : xs[e];
                                     } else {
                                         const double ar = fa_fabs(r);
                                         tl += ar;
-                                        mxr = ar > mxr ? ar : mxr;
+                                        mxr = __builtin_fmax(mxr, ar);  // one v_max_f64 (|r| as a source modifier) instead of compare + two selects
                                         rs[e] = (int)r;
                                     }
 #pragma unroll
