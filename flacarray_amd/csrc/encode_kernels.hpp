@@ -48,7 +48,42 @@ struct EncodeArgs {
     uint32_t* frame_bytes;  // [n_stream*nframes]
     FrameInfo* info;        // [n_stream*nframes] or null
     unsigned long long* stamps;  // diagnostic build (-DFA_STAMPS): per-phase cycle sums
+    const uint4* hdr;       // [nframes] frame header fields by frame number (see frame_header_entry)
 };
+
+// Frame header of frame number f (RFC 9639 9.1) as the fields the preamble writer ORs into the ring.
+// It depends on (f, blocksize, channels) only, so the host tabulates it once per encode call instead
+// of every wave deriving UTF-8 and CRC-8 with ~400 scalar instructions.
+//   x: sync | blocksize code | sample-rate code | channel / sample-size byte (32 bits)
+//   y: first (up to 4) bytes of the UTF-8 coded frame number
+//   z: remaining UTF-8 bytes (low 16 bits) | explicit blocksize bytes (high 16 bits)
+//   w: CRC-8 | bits of y << 8 | bits of the low half of z << 16 | bits of the high half of z << 24
+FA_HD uint4 frame_header_entry(uint64_t fn, int bs, int nch) {
+    const int bsc = blocksize_code(bs);
+    const uint32_t b2 = (uint32_t)((bsc << 4) | 9);
+    const uint32_t b3 = ((uint32_t)(nch - 1) << 4) | 0x0Eu;  // mono or two independent channels, 32 bits per sample, reserved 0
+    const int nbu = (fn < 0x80) ? 1 : (fn < 0x800) ? 2 : (fn < 0x10000) ? 3 : (fn < 0x200000) ? 4 : (fn < 0x4000000) ? 5 : 6;
+    uint64_t ub = fn;  // UTF-8 coded frame number, big-endian in the low nbu bytes
+    if (nbu > 1) {
+        ub = ((0xFF00u >> nbu) & 0xFFu) | (fn >> (6 * (nbu - 1)));
+        for (int i = 1; i < nbu; ++i) ub = (ub << 8) | 0x80u | ((fn >> (6 * (nbu - 1 - i))) & 0x3Fu);
+    }
+    uint8_t c8 = crc8_byte(crc8_byte(0, 0xFF), 0xF8);
+    c8 = crc8_byte(c8, (uint8_t)b2);
+    c8 = crc8_byte(c8, (uint8_t)b3);
+    for (int i = nbu - 1; i >= 0; --i) c8 = crc8_byte(c8, (uint8_t)(ub >> (8 * i)));
+    uint32_t bsv = 0, nb3 = 0;
+    if (bsc == 6) { c8 = crc8_byte(c8, (uint8_t)(bs - 1)); bsv = (uint32_t)(bs - 1); nb3 = 8; }
+    else if (bsc == 7) { c8 = crc8_byte(c8, (uint8_t)((bs - 1) >> 8)); c8 = crc8_byte(c8, (uint8_t)(bs - 1)); bsv = (uint32_t)(bs - 1); nb3 = 16; }
+    const int n1 = nbu > 4 ? 4 : nbu;
+    const uint32_t nb1 = 8u * (uint32_t)n1, nb2 = 8u * (uint32_t)(nbu - n1);
+    uint4 e;
+    e.x = 0xFFF80000u | (b2 << 8) | b3;
+    e.y = (uint32_t)(ub >> (8 * (nbu - n1)));
+    e.z = ((uint32_t)ub & ((1u << nb2) - 1u)) | (bsv << 16);
+    e.w = (uint32_t)c8 | (nb1 << 8) | (nb2 << 16) | (nb3 << 24);
+    return e;
+}
 
 #ifdef FA_STAMPS
 __device__ __forceinline__ unsigned long long fa_memtime() {
@@ -517,14 +552,9 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
         for (int i = lane; i < kRingWords; i += 64) ring[i] = 0;
         if (lane == 0) ring[kRingWords] = 0;
     }
-    // frame header bit count (needed for the exact subframe size): 8*(4 + utf8 + bs bytes + 1)
-    uint32_t fh_bits;
-    {
-        const uint64_t fn = (uint64_t)f;
-        int nb = (fn < 0x80) ? 1 : (fn < 0x800) ? 2 : (fn < 0x10000) ? 3 : (fn < 0x200000) ? 4 : (fn < 0x4000000) ? 5 : 6;
-        const int bsc = blocksize_code(bs);
-        fh_bits = 8u * (uint32_t)(4 + nb + (bsc == 6 ? 1 : bsc == 7 ? 2 : 0) + 1);
-    }
+    // frame header fields of this frame number (tabulated by the host) and their bit count
+    const uint4 fhe = a.hdr[f];
+    const uint32_t fh_bits = 32u + ((fhe.w >> 8) & 0xFFu) + ((fhe.w >> 16) & 0xFFu) + (fhe.w >> 24) + 8u;
 
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
@@ -1076,23 +1106,6 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
             atomicOr(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ring) + a0 + 4), (uint32_t)X);  // may be the mirror word
         };
         {
-            // wave-uniform header bytes and their CRC-8
-            const int bsc = blocksize_code(bs);
-            const uint32_t b2 = (uint32_t)((bsc << 4) | 9);
-            const uint64_t fn = (uint64_t)f;
-            const int nbu = (fn < 0x80) ? 1 : (fn < 0x800) ? 2 : (fn < 0x10000) ? 3 : (fn < 0x200000) ? 4 : (fn < 0x4000000) ? 5 : 6;
-            uint64_t ub = fn;  // UTF-8 coded frame number, big-endian in the low nbu bytes
-            if (nbu > 1) {
-                ub = ((0xFF00u >> nbu) & 0xFFu) | (fn >> (6 * (nbu - 1)));
-                for (int i = 1; i < nbu; ++i) ub = (ub << 8) | 0x80u | ((fn >> (6 * (nbu - 1 - i))) & 0x3Fu);
-            }
-            uint8_t c8 = crc8_byte(crc8_byte(0, 0xFF), 0xF8);
-            c8 = crc8_byte(c8, (uint8_t)b2);
-            constexpr uint32_t b3 = ((uint32_t)(NCH - 1) << 4) | 0x0Eu;  // mono or two independent channels, 32 bits per sample, reserved 0
-            c8 = crc8_byte(c8, (uint8_t)b3);
-            for (int i = nbu - 1; i >= 0; --i) c8 = crc8_byte(c8, (uint8_t)(ub >> (8 * i)));
-            if (bsc == 6) c8 = crc8_byte(c8, (uint8_t)(bs - 1));
-            else if (bsc == 7) { c8 = crc8_byte(c8, (uint8_t)((bs - 1) >> 8)); c8 = crc8_byte(c8, (uint8_t)(bs - 1)); }
             const int tc = (type == 0) ? 0x00 : (type == 1) ? 0x01 : (type == 2) ? (0x08 | order) : (0x20 | (order - 1));
             const uint32_t smask = (bps == 32) ? 0xffffffffu : ((1u << bps) - 1u);
             const int nwarm = (type == 0) ? 1 : (type >= 2) ? order : 0;
@@ -1101,14 +1114,14 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
             static_assert(kL_rice < 64, "preamble fields must fit the wave");
             uint32_t fv = 0, fnb = 0;
             const bool fh = (ch == 0);  // the frame header precedes the first subframe only
-            if (lane == 0) { if (fh) { fv = 0xFFF80000u | (b2 << 8) | b3; fnb = 32; } }
-            else if (lane == 1) { if (fh) { const int n1 = nbu > 4 ? 4 : nbu; fv = (uint32_t)(ub >> (8 * (nbu - n1))); fnb = 8u * (uint32_t)n1; } }
-            else if (lane == 2) { if (fh && nbu > 4) { fnb = 8u * (uint32_t)(nbu - 4); fv = (uint32_t)ub & ((1u << fnb) - 1u); } }
-            else if (lane == 3) { if (fh) { if (bsc == 6) { fv = (uint32_t)(bs - 1); fnb = 8; } else if (bsc == 7) { fv = (uint32_t)(bs - 1); fnb = 16; } } }
+            if (lane == 0) { if (fh) { fv = fhe.x; fnb = 32; } }
+            else if (lane == 1) { if (fh) { fv = fhe.y; fnb = (fhe.w >> 8) & 0xFFu; } }
+            else if (lane == 2) { if (fh) { fv = fhe.z & 0xFFFFu; fnb = (fhe.w >> 16) & 0xFFu; } }
+            else if (lane == 3) { if (fh) { fv = fhe.z >> 16; fnb = fhe.w >> 24; } }
             else if (lane == 4) {
                 fv = (uint32_t)((tc << 1) | (wasted ? 1 : 0));
                 fnb = 8;
-                if (fh) { fv |= (uint32_t)c8 << 8; fnb = 16; }
+                if (fh) { fv |= (fhe.w & 0xFFu) << 8; fnb = 16; }
             }
             else if (lane == 5) { if (wasted) { fv = 1; fnb = (uint32_t)wasted; } }  // unary: wasted-1 zeros, then 1
             else if (lane < kL_lpc) { if (lane - kL_warm < nwarm) { fv = (uint32_t)smp[smp_idx(lane - kL_warm)] & smask; fnb = (uint32_t)bps; } }

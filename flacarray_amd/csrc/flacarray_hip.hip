@@ -63,6 +63,7 @@ struct DeviceState {
     size_t scratch_bytes[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 std::map<int, DeviceState> g_dev;
+uint64_t g_scratch_epoch = 1;  // bumped whenever a scratch slot is (re)allocated or released: cached contents are then stale
 
 DeviceState* dev_state() {
     int d = 0;
@@ -79,6 +80,7 @@ int get_scratch(int slot, size_t bytes, void** out) {
         if (st->scratch[slot]) (void)hipFree(st->scratch[slot]);
         st->scratch[slot] = nullptr;
         st->scratch_bytes[slot] = 0;
+        g_scratch_epoch++;
         size_t want = bytes + (bytes >> 3) + 256;
         if (hipMalloc(&st->scratch[slot], want) != hipSuccess) {
             if (hipMalloc(&st->scratch[slot], bytes) != hipSuccess) return FA_ERROR_ALLOC | FA_ERROR_DEVICE;
@@ -404,11 +406,12 @@ void fa_release_scratch(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     DeviceState* st = dev_state();
     if (!st) return;
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 12; ++i) {
         if (st->scratch[i]) (void)hipFree(st->scratch[i]);
         st->scratch[i] = nullptr;
         st->scratch_bytes[i] = 0;
     }
+    g_scratch_epoch++;
 }
 
 int64_t fa_encode_workspace_bytes(int64_t n_stream, int64_t stream_size, uint32_t level) {
@@ -446,6 +449,28 @@ static int encode_device_begin(const int32_t* d_data, int nch, int64_t n_stream,
     a.frame_bytes = reinterpret_cast<uint32_t*>(ws + pl.off_fbytes);
     a.info = reinterpret_cast<FrameInfo*>(d_info);
     a.stamps = nullptr;
+    {
+        // frame header fields by frame number: tabulated on the host, cached on the device
+        static std::vector<uint4> h_hdr;
+        static int64_t c_nf = -1;
+        static int c_B = 0, c_tail = 0, c_nch = 0, c_dev = -1;
+        static void* c_dp = nullptr;
+        static uint64_t c_epoch = 0;
+        int dev = 0;
+        FA_HIP_TRY(hipGetDevice(&dev));
+        void* dp = nullptr;
+        rc = get_scratch(9, (size_t)pl.nf * sizeof(uint4) + 256, &dp);
+        if (rc) return rc;
+        if (c_nf != pl.nf || c_B != a.B || c_tail != a.tail_bs || c_nch != nch || c_dev != dev || c_dp != dp || c_epoch != g_scratch_epoch) {
+            h_hdr.resize((size_t)pl.nf);
+            for (int64_t f = 0; f < pl.nf; ++f)
+                h_hdr[(size_t)f] = frame_header_entry((uint64_t)f, (f == pl.nf - 1) ? a.tail_bs : a.B, nch);
+            FA_HIP_TRY(hipMemcpyAsync(dp, h_hdr.data(), (size_t)pl.nf * sizeof(uint4), hipMemcpyHostToDevice, st));
+            FA_HIP_TRY(hipStreamSynchronize(st));  // h_hdr is reused by the next call
+            c_nf = pl.nf; c_B = a.B; c_tail = a.tail_bs; c_nch = nch; c_dev = dev; c_dp = dp; c_epoch = g_scratch_epoch;
+        }
+        a.hdr = reinterpret_cast<const uint4*>(dp);
+    }
 #ifdef FA_STAMPS
     {
         void* sp = nullptr;
