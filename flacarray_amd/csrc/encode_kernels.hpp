@@ -534,7 +534,8 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
 
     const int lane = threadIdx.x;
     const int64_t g = blockIdx.x;
-    const int64_t s = g / a.nframes;
+    // (the host keeps n_stream * nframes below 2^31: a 32-bit division, not the 64-bit software one)
+    const int64_t s = (int64_t)((uint32_t)g / (uint32_t)a.nframes);
     const int64_t f = g - s * a.nframes;
     const int bs = (f == a.nframes - 1) ? a.tail_bs : a.B;
     const int32_t* src = a.data + (s * a.stream_size + f * (int64_t)a.B) * NCH;
@@ -1186,7 +1187,9 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
             }
         } else if (type >= 2) {
             const uint32_t ps = (uint32_t)(bs >> porder);
-            const uint32_t magic = (uint32_t)((0x100000000ULL + ps - 1) / ps);  // floor(gi/ps) = umulhi(gi, magic)
+            // floor(gi / ps) = umulhi(gi, magic); ps is a power of two for full frames (no 64-bit division then)
+            const uint32_t magic = ((ps & (ps - 1u)) == 0u) ? (uint32_t)(0x100000000ULL >> (31 - __clz((int)ps)))
+                                                           : (uint32_t)((0x100000000ULL + ps - 1) / ps);
             // GUARD: the row may hold warm-up samples or reach past the end of the frame
             auto rice_row = [&](auto guard_tag, int j) __attribute__((always_inline)) -> bool {
                 constexpr bool GUARD = decltype(guard_tag)::value;
