@@ -49,6 +49,7 @@ struct EncodeArgs {
     FrameInfo* info;        // [n_stream*nframes] or null
     unsigned long long* stamps;  // diagnostic build (-DFA_STAMPS): per-phase cycle sums
     const uint4* hdr;       // [nframes] frame header fields by frame number (see frame_header_entry)
+    int32_t pmax_full, pmax_tail;  // max_porder_for(B / tail_bs, max_porder, 0): the part that does not depend on the predictor order
 };
 
 // Frame header of frame number f (RFC 9639 9.1) as the fields the preamble writer ORs into the ring.
@@ -780,7 +781,13 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
         FA_STAMP(2);
         int po_fix = 0, k_fix = 0;
         const double tl_fix = (fo == 0) ? tot0 : (fo == 1) ? tot1 : (fo == 2) ? tot2 : (fo == 3) ? tot3 : tot4;
-        const int pmax_fix = max_porder_for(bs, a.max_porder, fo < 0 ? 0 : fo);
+        const int pmax_geo = (bs == a.B) ? a.pmax_full : a.pmax_tail;  // block size and level only: computed by the host
+        auto pmax_for = [&](int pred_order) __attribute__((always_inline)) {
+            int pm = pmax_geo;
+            while (pm > 0 && (bs >> pm) <= pred_order) pm--;
+            return pm;
+        };
+        const int pmax_fix = pmax_for(fo < 0 ? 0 : fo);
         // Full frames with modest sums (the common case): the fixed predictor's partition search is
         // branch-free and is issued together with the autocorrelation loop below, which hides its
         // scans, gathers and lane reads.  Otherwise it runs here, on its own.
@@ -1011,7 +1018,7 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                         FA_STAMP(7);
                         lds_is_residual = true;
                         const double MX = wave_max_f64(mxr);
-                        const int pmax = max_porder_for(bs, a.max_porder, lo);
+                        const int pmax = pmax_for(lo);
                         int po_l = 0, k_l = 0;
                         const uint64_t rbits = rice_search_all(active ? (uint64_t)tl : 0, bs, lo, pmax, lane, &po_l, &k_l);
                         if (MX <= 2147483647.0) {

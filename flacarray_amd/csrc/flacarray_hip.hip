@@ -449,6 +449,8 @@ static int encode_device_begin(const int32_t* d_data, int nch, int64_t n_stream,
     a.frame_bytes = reinterpret_cast<uint32_t*>(ws + pl.off_fbytes);
     a.info = reinterpret_cast<FrameInfo*>(d_info);
     a.stamps = nullptr;
+    a.pmax_full = max_porder_for(a.B, a.max_porder, 0);
+    a.pmax_tail = max_porder_for(a.tail_bs, a.max_porder, 0);
     {
         // frame header fields by frame number: tabulated on the host, cached on the device
         static std::vector<uint4> h_hdr;
