@@ -50,6 +50,7 @@ struct EncodeArgs {
     unsigned long long* stamps;  // diagnostic build (-DFA_STAMPS): per-phase cycle sums
     const uint4* hdr;       // [nframes] frame header fields by frame number (see frame_header_entry)
     int32_t pmax_full, pmax_tail;  // max_porder_for(B / tail_bs, max_porder, 0): the part that does not depend on the predictor order
+    double escale_full, escale_tail;  // 0.5 / blocksize (best_lpc_order's error scale), divided once on the host
 };
 
 // Frame header of frame number f (RFC 9639 9.1) as the fields the preamble writer ORs into the ring.
@@ -923,7 +924,7 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                         double mybits = 1e300;
                         if (lane < usable) {
                             const double e = err[lane];
-                            const double error_scale = 0.5 / (double)bs;
+                            const double error_scale = (bs == a.B) ? a.escale_full : a.escale_tail;  // 0.5 / bs
                             double bpsv;
                             if (e > 0.0) {
                                 bpsv = 0.5 * det_log2(error_scale * e);

@@ -451,6 +451,8 @@ static int encode_device_begin(const int32_t* d_data, int nch, int64_t n_stream,
     a.stamps = nullptr;
     a.pmax_full = max_porder_for(a.B, a.max_porder, 0);
     a.pmax_tail = max_porder_for(a.tail_bs, a.max_porder, 0);
+    a.escale_full = 0.5 / (double)a.B;
+    a.escale_tail = 0.5 / (double)a.tail_bs;
     {
         // frame header fields by frame number: tabulated on the host, cached on the device
         static std::vector<uint4> h_hdr;
