@@ -188,92 +188,69 @@ class FlacArray:
         return self._typestr
 
     # ---- numpy-style selection -> decode ----
-    @staticmethod
-    def _slice_nelem(slc, dim):
-        start, stop, step = slc.indices(dim)
-        return max((stop - start) // step, 0)
+    def _plan_selection(self, raw_key):
+        """Turn a numpy-style key into (result shape, keep mask over the streams, first, last sample).
 
-    def _get_full_key(self, key):
-        """Pad the user key to one entry per dimension of the local shape (array.py:297-337)."""
+        Same results as the reference's key handling (array.py:297-407): integers drop their axis,
+        slices keep it, an out-of-range integer on a leading axis gives an empty result instead of an
+        IndexError, the stream axis takes an integer or a step-1 slice, and the streams are picked
+        through a boolean mask (so a negative leading step does not reverse their order)."""
+        key = raw_key if isinstance(raw_key, tuple) else (raw_key,)
+        if self._flatten_single:  # a 1-D array: the user's key addresses the samples only
+            if len(key) != 1:
+                raise ValueError(f"Slice key {raw_key} is not valid for single, flattened stream.")
+            key = (0,) + key
         ndim = len(self._local_shape)
-        if self._flatten_single:
-            if isinstance(key, tuple):
-                if len(key) != 1:
-                    raise ValueError(f"Slice key {key} is not valid for single, flattened stream.")
-                full_key = [0, key[0]]
-            else:
-                full_key = [0, key]
-        else:
-            full_key = list(key) if isinstance(key, tuple) else [key]
-        if len(full_key) > ndim:
-            raise ValueError(f"Invalid slice key {key}, too many dimensions")
-        full_key.extend([slice(None)] * (ndim - len(full_key)))
-        return full_key
+        if len(key) > ndim:
+            raise ValueError(f"Invalid slice key {raw_key}, too many dimensions")
+        key = key + (slice(None),) * (ndim - len(key))
+        *lead_key, samp_key = key
 
-    def _get_leading_axes(self, full_key):
-        """Output leading shape and bool keep-mask for the leading axes (array.py:339-378)."""
-        if self._flatten_single:
-            keep = np.zeros(self._leading_shape, dtype=bool)
-            keep[0] = True
-            return (), keep
-        leading_shape = []
-        keep_slice = []
-        for axis, axkey in enumerate(full_key[:-1]):
-            if isinstance(axkey, (int, np.integer)):
-                if axkey < 0 or axkey >= self._local_shape[axis]:
-                    leading_shape.append(0)  # out of range: a zero-length result
-            else:
-                leading_shape.append(self._slice_nelem(axkey, self._local_shape[axis]))
-            keep_slice.append(axkey)
-        if len(keep_slice) == 0:
-            return tuple(leading_shape), None
-        if len(keep_slice) != len(self._leading_shape):
-            raise ValueError(f"keep_view {keep_slice} does not match leading dimensions {len(self._leading_shape)}")
-        keep = np.zeros(self._leading_shape, dtype=bool)
-        if 0 not in leading_shape:
-            keep[tuple(keep_slice)] = True
-        return tuple(leading_shape), keep
-
-    def _get_sample_axis(self, full_key):
-        """(first, last, sample_shape) of the stream-axis selection (array.py:380-407)."""
-        sample_key = full_key[-1]
-        if sample_key is None:
-            return (0, self._stream_size, (self._stream_size,))
-        if isinstance(sample_key, slice):
-            start, stop, step = sample_key.indices(self._stream_size)
+        # stream axis
+        n = self._stream_size
+        if samp_key is None:
+            first, last, samp_shape = 0, n, (n,)
+        elif isinstance(samp_key, slice):
+            first, last, step = samp_key.indices(n)
             if step != 1:
                 raise ValueError("Only stride==1 supported on stream slices")
-            if stop - start <= 0:
-                return (0, 0, (0,))
-            return (start, stop, (stop - start,))
-        if isinstance(sample_key, (int, np.integer)):
-            return (sample_key, sample_key + 1, ())
-        raise ValueError("Stream dimension supports contiguous slices or single indices.")
+            if last <= first:
+                first, last = 0, 0
+            samp_shape = (last - first,)
+        elif isinstance(samp_key, (int, np.integer)):
+            first, last, samp_shape = samp_key, samp_key + 1, ()
+        else:
+            raise ValueError("Stream dimension supports contiguous slices or single indices.")
+
+        # leading axes
+        lead_shape = []
+        nothing = False
+        for k, dim in zip(lead_key, self._leading_shape):
+            if isinstance(k, (int, np.integer)):
+                if not 0 <= k < dim:
+                    lead_shape.append(0)
+                    nothing = True
+            else:
+                lo, hi, st = k.indices(dim)
+                lead_shape.append(len(range(lo, hi, st)))
+        keep = None
+        if len(lead_key) > 0:
+            keep = np.zeros(self._leading_shape, dtype=bool)
+            if not nothing:
+                keep[tuple(lead_key)] = True
+        return tuple(lead_shape) + samp_shape, keep, first, last
 
     def __getitem__(self, raw_key):
-        """Decompress a selection on the fly; result shape equals numpy's for the same key."""
-        key = self._get_full_key(raw_key)
-        leading_shape, keep = self._get_leading_axes(key)
-        first, last, sample_shape = self._get_sample_axis(key)
-        full_shape = leading_shape + sample_shape
-        n_total = 0 if len(full_shape) == 0 else int(np.prod(full_shape))
-        if len(full_shape) == 0 and not (0 in leading_shape):
-            n_total = 1  # a single element: every axis indexed by an integer
-        if n_total == 0:
-            return np.zeros(full_shape, dtype=self._dtype)
+        """Decompress a selection on the fly; the result has numpy's shape for the same key."""
+        shape, keep, first, last = self._plan_selection(raw_key)
+        if 0 in shape:
+            return np.zeros(shape, dtype=self._dtype)
         arr, _ = array_decompress_slice(
-            self._compressed,
-            self._stream_size,
-            self._stream_starts,
-            self._stream_nbytes,
-            stream_offsets=self._stream_offsets,
-            stream_gains=self._stream_gains,
-            keep=keep,
-            first_stream_sample=first,
-            last_stream_sample=last,
+            self._compressed, self._stream_size, self._stream_starts, self._stream_nbytes, stream_offsets=self._stream_offsets,
+            stream_gains=self._stream_gains, keep=keep, first_stream_sample=first, last_stream_sample=last,
             is_int64=self._is_int64,
         )
-        return arr.reshape(full_shape)
+        return arr.reshape(shape)
 
     def __delitem__(self, key):
         raise RuntimeError("Cannot delete individual streams")

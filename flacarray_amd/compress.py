@@ -1,50 +1,62 @@
-"""array_compress (reference: src/flacarray/compress.py:12-84)."""
+"""array_compress: dtype dispatch in front of the encoder (reference: src/flacarray/compress.py:12-84).
+
+Same call signature, return tuple and error behaviour as the reference; the work happens in
+`float_to_int` (K1) and `encode_flac` (K3-K5) on the GPU.
+"""
 import numpy as np
 
 from .libflacarray import encode_flac
 from .utils import float_to_int, function_timer
+
+_INT_KINDS = (np.dtype(np.int32), np.dtype(np.int64))
+_FLOAT_KINDS = (np.dtype(np.float32), np.dtype(np.float64))
+
+
+def _per_stream_quanta(quanta, leading_shape, dtype):
+    """Broadcast a scalar quanta over the streams, or check the shape of an array of them.
+
+    (The reference trips over array-valued quanta here, compress.py:61-63 reads `.shape` of an int;
+    per-stream quanta otherwise only work through float_to_int.  They are accepted.)"""
+    if not hasattr(quanta, "__len__"):
+        return np.full(leading_shape, quanta, dtype=dtype)
+    per_stream = np.asarray(quanta)
+    if per_stream.shape != leading_shape:
+        msg = "If not a scalar, quanta must have the same shape as the "
+        msg += "leading dimensions of the array"
+        raise ValueError(msg)
+    return per_stream.astype(dtype)
 
 
 @function_timer
 def array_compress(arr, level=5, quanta=None, precision=None, use_threads=False):
     """Compress a numpy array with optional floating point conversion.
 
-    int32 input: offsets and gains are None.  float32 input: exactly one of `quanta`
-    (scalar or one value per stream) or `precision` is required.  Returns
-    (compressed bytes, stream starts, stream nbytes, stream offsets, stream gains) with the
-    auxiliary arrays shaped like the leading dimensions of `arr` (1 element for one stream).
+    Integer input (int32, int64) is compressed as is and the last two elements of the result are None.
+    Float input (float32, float64) needs exactly one of `quanta` (scalar or one value per stream)
+    and `precision`; it is converted to integers with a per-stream offset and gain first.
 
-    Unlike compress.py:61-63 an array-valued `quanta` is accepted (the reference raises
-    AttributeError there; per-stream quanta otherwise only work through float_to_int).
+    Returns (compressed bytes, stream starts, stream nbytes, stream offsets, stream gains); the
+    auxiliary arrays have the leading shape of `arr` (one element for a single stream).
     """
     if arr.size == 0:
         raise ValueError("Cannot compress a zero-sized array!")
-    leading_shape = arr.shape[:-1]
+    kind = arr.dtype
 
-    if arr.dtype == np.dtype(np.float32) or arr.dtype == np.dtype(np.float64):
-        if quanta is None and precision is None:
-            msg = f"Compressing floating point data ('{arr.dtype}') "
-            msg += "requires specifying either quanta or precision."
-            raise RuntimeError(msg)
-        if quanta is not None:
-            if precision is not None:
-                raise RuntimeError("Cannot set both quanta and precision")
-            if hasattr(quanta, "__len__"):
-                dquanta = np.asarray(quanta)
-                if dquanta.shape != leading_shape:
-                    msg = "If not a scalar, quanta must have the same shape as the "
-                    msg += "leading dimensions of the array"
-                    raise ValueError(msg)
-                dquanta = dquanta.astype(arr.dtype)
-            else:
-                dquanta = quanta * np.ones(leading_shape, dtype=arr.dtype)
-        else:
-            dquanta = None
-        idata, foff, gains = float_to_int(arr, quanta=dquanta, precision=precision)
-        (compressed, starts, nbytes) = encode_flac(idata, level, use_threads=use_threads)
-        return (compressed, starts, nbytes, foff, gains)
-    elif arr.dtype == np.dtype(np.int32) or arr.dtype == np.dtype(np.int64):
-        (compressed, starts, nbytes) = encode_flac(np.ascontiguousarray(arr), level, use_threads=use_threads)
+    if kind in _INT_KINDS:
+        compressed, starts, nbytes = encode_flac(np.ascontiguousarray(arr), level, use_threads=use_threads)
         return (compressed, starts, nbytes, None, None)
-    else:
+
+    if kind not in _FLOAT_KINDS:
         raise ValueError(f"Unsupported data type '{arr.dtype}'")
+
+    if quanta is None and precision is None:
+        msg = f"Compressing floating point data ('{arr.dtype}') "
+        msg += "requires specifying either quanta or precision."
+        raise RuntimeError(msg)
+    if quanta is not None and precision is not None:
+        raise RuntimeError("Cannot set both quanta and precision")
+
+    stream_quanta = None if quanta is None else _per_stream_quanta(quanta, arr.shape[:-1], kind)
+    ints, offsets, gains = float_to_int(arr, quanta=stream_quanta, precision=precision)
+    compressed, starts, nbytes = encode_flac(ints, level, use_threads=use_threads)
+    return (compressed, starts, nbytes, offsets, gains)
