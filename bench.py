@@ -74,7 +74,7 @@ def cpu_baseline(n_samp, seconds_budget=25.0):
     # a one-GPU box gives this process a CPU share of 16 cores whatever the host's core count is
     threads = min(O.lib().oracle_num_threads(), int(os.environ.get("FA_BENCH_CPU_THREADS", "16")))
     O.lib().oracle_set_threads(threads)
-    n_ch = 4 * threads
+    n_ch = 16 * threads  # ~15-20 s of CPU work at 16 threads
     rng = np.random.default_rng(123456789)
     t = np.arange(n_samp)
     f = 5.0 / n_samp
