@@ -1058,10 +1058,10 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
                 hbw |= (xd < 0.0) ? (1u << (i & 31)) : 0u;
             }
             h[u % MO] = xd;
-            tile[(i & (kTileW - 1)) * kLaneStride + (lane ^ (((i & (kTileW - 1)) >> 2) * kTileSwz))] = (int32_t)((uint32_t)wrap32(xd) << wasted);
+            tile[u * kLaneStride + (lane ^ ((u >> 2) * kTileSwz))] = (int32_t)((uint32_t)wrap32(xd) << wasted);
         } else if constexpr (GUARD) {
             // warm-up sample 16..31 (orders above 16): its value sits in the history
-            if (i < bs && i >= kTileW) tile[(i & (kTileW - 1)) * kLaneStride + (lane ^ (((i & (kTileW - 1)) >> 2) * kTileSwz))] = (int32_t)((uint32_t)wrap32(h[u % MO]) << wasted);
+            if (i < bs && i >= kTileW) tile[u * kLaneStride + (lane ^ ((u >> 2) * kTileSwz))] = (int32_t)((uint32_t)wrap32(h[u % MO]) << wasted);
         }
     };
 
@@ -1130,7 +1130,10 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
     };
 
     const int bs_max = a.B;  // uniform loop bound (B >= every frame's blocksize)
-    constexpr int MACRO = (MO > 16) ? MO : 16;
+    // a macro step is one output tile (32 samples): the tile index of every sample is then a compile-time
+    // constant, so the swizzled LDS address of its store costs no instructions inside the loop
+    constexpr int MACRO = kTileW;
+    static_assert(MACRO % MO == 0 && MACRO % 16 == 0, "history rotation and tile must divide the macro step");
     auto macro_step = [&](auto guard_tag, int i0) __attribute__((always_inline)) {
         static_for<MACRO>([&](auto ut) __attribute__((always_inline)) {
             constexpr int u = decltype(ut)::value;
@@ -1141,9 +1144,7 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
                 topup();
             }
             sample(guard_tag, ut, i);
-            if constexpr ((u & 15) == 15) {
-                if ((i & (kTileW - 1)) == kTileW - 1) flush_tile(i & ~(kTileW - 1));  // uniform
-            }
+            if constexpr (u == MACRO - 1) flush_tile(i0);
         });
     };
     // guarded head (warm-up zone), unguarded main part, guarded tail (frames shorter than B).
