@@ -976,8 +976,10 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
     int kf = (escw < 0) ? k : 64;  // fast-path key: z + kf < 32  <=>  plain Rice code of at most 32 bits
 
     // one sample of every lane.  GUARD: lanes may be in warm-up or past their frame's end.
-    auto sample = [&](auto guard_tag, auto u_tag, int i) __attribute__((always_inline)) {
+    // PART: a partition boundary may fall inside this macro step (decided once per step for the wave)
+    auto sample = [&](auto guard_tag, auto part_tag, auto u_tag, int i) __attribute__((always_inline)) {
         constexpr bool GUARD = decltype(guard_tag)::value;
+        constexpr bool PART = decltype(part_tag)::value;
         constexpr int u = decltype(u_tag)::value;
         bool live = true;
         if constexpr (GUARD) {
@@ -986,7 +988,7 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
         }
         if (live) {
             // rare events are tested wave-wide first, so the common case carries no exec-mask code
-            if (__builtin_expect(__any(pleft <= 0), 0)) {
+            if (PART && __builtin_expect(__any(pleft <= 0), 0)) {
                 if (pleft <= 0) {
                     const ParamRet pr = slow_param(cbase, lim16, ring, bitpos, next_chunk, plen, esc);
                     k = (int)pr.k;
@@ -1046,7 +1048,7 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
             }
             bitpos = nbp;
             ring_words(ring, bitpos, pw0, pw1, pw2);  // LDS latency hides behind the prediction below
-            pleft--;
+            if constexpr (PART) pleft--;
             // every term is an exact integer in double, so the order is free: the newest sample enters
             // last and the loop-carried chain is one fma + scale + floor + add
             double sum = 0.0;
@@ -1134,7 +1136,7 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
     // constant, so the swizzled LDS address of its store costs no instructions inside the loop
     constexpr int MACRO = kTileW;
     static_assert(MACRO % MO == 0 && MACRO % 16 == 0, "history rotation and tile must divide the macro step");
-    auto macro_step = [&](auto guard_tag, int i0) __attribute__((always_inline)) {
+    auto macro_step = [&](auto guard_tag, auto part_tag, int i0) __attribute__((always_inline)) {
         static_for<MACRO>([&](auto ut) __attribute__((always_inline)) {
             constexpr int u = decltype(ut)::value;
             const int i = i0 + u;
@@ -1143,7 +1145,7 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
                 // least 64 are resident after this top-up -> the sample code needs no residency test
                 topup();
             }
-            sample(guard_tag, ut, i);
+            sample(guard_tag, part_tag, ut, i);
             if constexpr (u == MACRO - 1) flush_tile(i0);
         });
     };
@@ -1158,9 +1160,18 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
     for (int pass = 0; pass < 2; ++pass) {
         const int g_lo = pass == 0 ? 0 : main_hi;
         const int g_hi = pass == 0 ? main_lo : end;
-        for (int i0 = g_lo; i0 < g_hi; i0 += MACRO) macro_step(std::true_type{}, i0);
-        if (pass == 0)
-            for (int i0 = main_lo; i0 < main_hi; i0 += MACRO) macro_step(std::false_type{}, i0);
+        for (int i0 = g_lo; i0 < g_hi; i0 += MACRO) macro_step(std::true_type{}, std::true_type{}, i0);
+        if (pass == 0) {
+            for (int i0 = main_lo; i0 < main_hi; i0 += MACRO) {
+                // no lane's partition ends inside this step: the per-sample boundary test and count are dropped
+                if (__any(pleft < MACRO)) {
+                    macro_step(std::false_type{}, std::true_type{}, i0);
+                } else {
+                    macro_step(std::false_type{}, std::false_type{}, i0);
+                    pleft -= MACRO;
+                }
+            }
+        }
     }
     }  // channel loop
     if constexpr (NCH == 2) {
