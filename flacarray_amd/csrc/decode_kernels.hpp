@@ -506,7 +506,8 @@ struct DecodeArgs {
 //                        most 64 bytes in 16 fast-path samples), so the per-sample code has no
 //                        refill branch: it re-reads its 96-bit window at `bitpos` from LDS
 //   tile  64 x 20 words  decoded samples, transposed so that HBM stores are 64-byte row pieces
-//   rows  64 descriptors output offset / valid range / (offset, 1/gain) of each lane's frame
+//   rows  (offset, 1/gain) of each lane's frame for the float32 instantiation; output offsets and valid
+//                        ranges stay in registers and travel by ds_bpermute
 // Rare paths (headers, warm-up, partition parameters, escapes, codes longer than 32 bits) go
 // through two out-of-line helpers that take and return the reader state by value, so the hot
 // loop keeps `bitpos` in a register.
@@ -699,12 +700,18 @@ __device__ __noinline__ BitsRet slow_sample(const uint8_t* cbase, const uint8_t*
 // tmp[(task * 2 + channel) * B + sample] (low 32 bits) plus one bit per sample for bit 32 (side
 // channels carry 33 bits); combine_channels_kernel undoes the stereo decorrelation and writes int64.
 template <int MO, int MO_DONE, bool F32, int NCH>
-__global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* flags) {
+#ifndef FA_K7_WAVES_ATTR
+#define FA_K7_WAVES_ATTR
+#endif
+__global__ __launch_bounds__(64) FA_K7_WAVES_ATTR void decode_frames_kernel(DecodeArgs a, int* flags) {
+    // tile width of this instantiation (shadows the namespace defaults): FA_TILE_W applies to the one-channel
+    // variants with a history of at most 16; the others need 32-sample tiles
+    constexpr int kTileW = (NCH == 1 && MO <= 16) ? FA_TILE_W : 32;
+    constexpr int kTileG = kTileW / 4;
+    constexpr int kTileSwz = 32 / kTileG;
     static_assert(NCH == 1 || (kTileW == 32 && !F32), "two-channel variant: 32-sample tiles, integer output");
     __shared__ __attribute__((aligned(16))) uint32_t rings[kDecRingWords * kLaneStride];
     __shared__ __attribute__((aligned(16))) int32_t tile[kTileW * kLaneStride];  // sample t of lane l at t*64 + (l ^ 8*(t>>2))
-    __shared__ int64_t row_out[64];
-    __shared__ int2 row_rng[64];
     __shared__ float2 row_fg[F32 ? 64 : 1];
     const int lane = threadIdx.x;
     const int64_t task = (int64_t)blockIdx.x * 64 + lane;
@@ -923,6 +930,10 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
         for (int j = 0; j < MO; ++j) c[j] = 0.0;
         scale = 1.0; order = 0; escw = bps; pleft = 0x7fffffff;
     }
+    // coefficients pre-scaled by 2^-shift: every product and partial sum keeps its significand (|sum| < 2^53),
+    // so floor(sum of (c 2^-shift) x) equals floor((sum of c x) 2^-shift) and the hot loop has no multiply by the scale
+#pragma unroll
+    for (int j = 0; j < MO; ++j) c[j] *= scale;
     // smallest blocksize in the wave decides where the guarded tail starts (idle lanes: huge)
     int bs_min = bs;
 #pragma unroll
@@ -936,8 +947,17 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
     int64_t row0;  // output element index of frame sample 0
     if constexpr (NCH == 2) row0 = (task * 2 + chn) * (int64_t)a.B;
     else row0 = out_off + (fstart - sl_first);
-    row_out[lane] = row0;
-    row_rng[lane] = make_int2(lo, hi);
+    // The store pass `it` of a tile has this lane write a piece of row it * (64 / kTileG) + lane / kTileG: that
+    // row's output offset is fetched from its owner lane once per frame and kept in registers (no LDS table:
+    // the LDS saved is what lets more waves share a CU); the valid range is fetched in the rare clipped path.
+    int64_t rout[kTileG];
+#pragma unroll
+    for (int it = 0; it < kTileG; ++it) {
+        const int r = it * (64 / kTileG) + (lane / kTileG);
+        const uint32_t rl = (uint32_t)__builtin_amdgcn_ds_bpermute(r << 2, (int)(uint32_t)(uint64_t)row0);
+        const uint32_t rh = (uint32_t)__builtin_amdgcn_ds_bpermute(r << 2, (int)(uint32_t)((uint64_t)row0 >> 32));
+        rout[it] = (int64_t)(((uint64_t)rh << 32) | rl);
+    }
     if constexpr (F32) {
         float og = 0.0f, cf = 1.0f;
         if (mode != 3) {
@@ -1050,11 +1070,11 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
             ring_words(ring, bitpos, pw0, pw1, pw2);  // LDS latency hides behind the prediction below
             if constexpr (PART) pleft--;
             // every term is an exact integer in double, so the order is free: the newest sample enters
-            // last and the loop-carried chain is one fma + scale + floor + add
+            // last and the loop-carried chain is one fma + floor + add
             double sum = 0.0;
 #pragma unroll
             for (int j = MO - 1; j >= 0; --j) sum = __builtin_fma(c[j], h[(u + MO - 1 - j) % MO], sum);
-            double xd = (double)r + fa_floor(sum * scale);
+            double xd = (double)r + fa_floor(sum);
             if constexpr (NCH == 2) {
                 xd += radd;
                 hbw |= (xd < 0.0) ? (1u << (i & 31)) : 0u;
@@ -1085,12 +1105,12 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
                 const int rsw = r ^ (cg * kTileSwz);
                 const int4 v = make_int4(tile[(cb + 0) * kLaneStride + rsw], tile[(cb + 1) * kLaneStride + rsw],
                                          tile[(cb + 2) * kLaneStride + rsw], tile[(cb + 3) * kLaneStride + rsw]);
-                *reinterpret_cast<int4*>(a.out_i32 + row_out[r] + tbase + cb) = v;
+                *reinterpret_cast<int4*>(a.out_i32 + rout[it] + tbase + cb) = v;
             }
             __builtin_amdgcn_wave_barrier();
             return;
         }
-#pragma unroll 4
+#pragma unroll
         for (int it = 0; it < kTileG; ++it) {
             const int r = it * kRowsPerPass + (lane / kTileG);
             const int cg = lane % kTileG;
@@ -1098,10 +1118,10 @@ __global__ __launch_bounds__(64) void decode_frames_kernel(DecodeArgs a, int* fl
             const int rsw = r ^ (cg * kTileSwz);  // the writer's swizzle
             const int4 v = make_int4(tile[(cb + 0) * kLaneStride + rsw], tile[(cb + 1) * kLaneStride + rsw], tile[(cb + 2) * kLaneStride + rsw],
                                      tile[(cb + 3) * kLaneStride + rsw]);
-            const int2 rg = row_rng[r];
+            const int2 rg = make_int2(__builtin_amdgcn_ds_bpermute(r << 2, lo), __builtin_amdgcn_ds_bpermute(r << 2, hi));
             const int si = tbase + cb;
             if (si + 3 >= rg.x && si < rg.y) {
-                const int64_t ob = row_out[r] + si;
+                const int64_t ob = rout[it] + si;
                 const bool fullv = (si >= rg.x) && (si + 3 < rg.y) && out_aligned && ((ob & 3) == 0);
                 if constexpr (F32) {
                     const float2 fg = row_fg[r];

@@ -520,7 +520,10 @@ __device__ __forceinline__ void load_frame(const int32_t* __restrict__ src, int 
 // low / high words, coded as two independent subframes (channel assignment 0b0001) one after the
 // other into the same bit ring.
 template <int MLO, int NCH = 1>
-__global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
+#ifndef FA_K3_WAVES_ATTR
+#define FA_K3_WAVES_ATTR
+#endif
+__global__ __launch_bounds__(64) FA_K3_WAVES_ATTR void encode_frames_kernel(EncodeArgs a) {
     constexpr int kScrWords = (NCH == 2) ? 256 : 0;  // analysis scratch: the ring holds live bits while channel 1 is analysed
 #ifdef FA_LDS_PAD
     __shared__ __attribute__((aligned(16))) int32_t lds[kLdsWords + kScrWords + FA_LDS_PAD];  // occupancy experiment
@@ -958,12 +961,14 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                     if (prec >= 2) ok = (quantize_coefs_t<MLO>(coef + (lo - 1) * MLO, lo, prec, qreg, &sh) == 0) ? 1 : 0;
                     FA_STAMP(6);
                     if (ok) {
+                        // coefficients pre-scaled by 2^-sh: products and partial sums keep their significands
+                        // (|sum of q*x| < 2^49), so floor(sum of (q 2^-sh) x) == floor((sum of q x) 2^-sh) exactly
+                        const double scale = bitsd((uint64_t)(1023 - sh) << 52);  // 2^-sh
                         double qd[MLO];
 #pragma unroll
-                        for (int j = 0; j < MLO; ++j) qd[j] = (double)qreg[j];
+                        for (int j = 0; j < MLO; ++j) qd[j] = (double)qreg[j] * scale;
                         // ---- P4: LPC residual in place + magnitude sums ----------------
                         double tl = 0.0, mxr = 0.0;
-                        const double scale = bitsd((uint64_t)(1023 - sh) << 52);  // 2^-sh
                         if (active) {
                             const int cbase = kChunkStride * (lane + 1);
                             const int g0 = kChunk * lane;
@@ -984,7 +989,7 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                                     double sum = 0.0;
 #pragma unroll
                                     for (int j = 0; j < MLO; ++j) sum = __builtin_fma(qd[j], hx[j], sum);
-                                    const double pred = fa_floor(sum * scale);
+                                    const double pred = fa_floor(sum);
                                     const double r = xd - pred;
                                     if constexpr (MASK) {
                                         const int gi = g0 + 4 * t + e;
@@ -1021,7 +1026,22 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
                         const double MX = wave_max_f64(mxr);
                         const int pmax = pmax_for(lo);
                         int po_l = 0, k_l = 0;
-                        const uint64_t rbits = rice_search_all(active ? (uint64_t)tl : 0, bs, lo, pmax, lane, &po_l, &k_l);
+                        uint64_t rbits;
+                        if (full && pmax <= 5 && __all(tl < 16777216.0)) {
+                            // the common case: the straight-line 32-bit search (same values as rice_search_all)
+                            FastRiceSearch fs;
+                            fs.start((uint32_t)tl, bs, lo, pmax, lane);
+                            fs.gather();
+                            fs.params();
+                            fs.totals();
+#pragma unroll
+                            for (int o = 5; o >= 0; --o) fs.order(o);
+                            po_l = fs.bpo;
+                            k_l = fs.kb;
+                            rbits = fs.best;
+                        } else {
+                            rbits = rice_search_all(active ? (uint64_t)tl : 0, bs, lo, pmax, lane, &po_l, &k_l);
+                        }
                         if (MX <= 2147483647.0) {
                             const uint64_t est = 8 + (uint64_t)wasted + 4 + 5 + (uint64_t)lo * (uint64_t)(prec + bps) + rbits;
                             if (est < best_bits) {
@@ -1258,8 +1278,63 @@ __global__ __launch_bounds__(64) void encode_frames_kernel(EncodeArgs a) {
             };
             if (!rice_row(std::true_type{}, 0)) overflow = true;
             if (full) {
-                for (int j = 1; j < nrows && !overflow; ++j)
-                    if (!rice_row(std::false_type{}, j)) overflow = true;
+                // Rows 1..15 of a full frame (partition size a power of two >= 64, no warm-up samples, no
+                // tail): the codes and the length scan of row j+1 are prepared before row j is written,
+                // so that the scan's dependent DPP chain and lane read overlap the writer's address
+                // arithmetic and LDS atomics instead of stalling the wave.
+                struct RowPrep {
+                    uint32_t u[4], q[4], k, lane_len, incl, total;
+                    bool newp;
+                };
+                const int l2ps = 31 - __clz((int)ps);
+                const int rowbase = smp_idx(4 * lane);  // smp_idx(kRow * j + 4 * lane) = rowbase + 4 * kChunkStride * j
+                auto rice_prep = [&](int j, RowPrep& R) __attribute__((always_inline)) {
+                    const uint32_t gb = (uint32_t)(kRow * j + 4 * lane);
+                    const int4 rv = *reinterpret_cast<const int4*>(&smp[rowbase + 4 * kChunkStride * j]);
+                    const int rs[4] = {rv.x, rv.y, rv.z, rv.w};
+                    R.k = kpar[gb >> l2ps];
+                    // gb > 0 here, so the short first partition (it starts at `order`) never opens in these rows
+                    R.newp = (gb & (ps - 1u)) == 0u;
+                    uint32_t len = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t u = ((uint32_t)rs[e] << 1) ^ (uint32_t)(rs[e] >> 31);
+                        uint32_t q = u >> R.k;
+                        if (e == 0) q += R.newp ? (uint32_t)plen : 0u;  // room for the partition's parameter
+                        R.u[e] = u;
+                        R.q[e] = q;
+                        len += q;
+                    }
+                    R.lane_len = len + 4u * (R.k + 1u);
+                    R.incl = wave_incl_scan_u32(R.lane_len);
+                    R.total = (uint32_t)__builtin_amdgcn_readlane((int)R.incl, 63);
+                };
+                auto rice_put = [&](const RowPrep& R) __attribute__((always_inline)) {
+                    const uint32_t k = R.k, kp1 = k + 1u;
+                    const uint32_t onek = 1u << k, mask = onek - 1u;
+                    const uint32_t p0 = pos + R.incl - R.lane_len;
+                    uint32_t p = p0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        put_bits(p + R.q[e], onek | (R.u[e] & mask), kp1);
+                        p += R.q[e] + kp1;
+                    }
+                    // (last, so that the four unconditional codes share a basic block with the next row's scan)
+                    if (R.newp) put_bits(p0, k, (uint32_t)plen);
+                };
+                if (!overflow) {
+                    RowPrep cur;
+                    rice_prep(1, cur);
+                    for (int j = 1; j < kMaxBlock / kRow; ++j) {
+                        if (cur.total > (uint32_t)kRowCapBits) { overflow = true; break; }
+                        RowPrep nxt;
+                        rice_prep(j < kMaxBlock / kRow - 1 ? j + 1 : j, nxt);  // (the last row is prepared twice, harmlessly)
+                        rice_put(cur);
+                        pos += cur.total;
+                        flush_blocks();
+                        cur = nxt;
+                    }
+                }
             } else {
                 for (int j = 1; j < nrows && !overflow; ++j)
                     if (!rice_row(std::true_type{}, j)) overflow = true;
