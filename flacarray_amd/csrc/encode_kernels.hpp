@@ -1323,16 +1323,22 @@ __global__ __launch_bounds__(64) FA_K3_WAVES_ATTR void encode_frames_kernel(Enco
                     if (R.newp) put_bits(p0, k, (uint32_t)plen);
                 };
                 if (!overflow) {
-                    RowPrep cur;
-                    rice_prep(1, cur);
-                    for (int j = 1; j < kMaxBlock / kRow; ++j) {
-                        if (cur.total > (uint32_t)kRowCapBits) { overflow = true; break; }
-                        RowPrep nxt;
-                        rice_prep(j < kMaxBlock / kRow - 1 ? j + 1 : j, nxt);  // (the last row is prepared twice, harmlessly)
-                        rice_put(cur);
-                        pos += cur.total;
+                    // two rows per trip, so that the two preparation records swap roles without register copies
+                    constexpr int kLast = kMaxBlock / kRow - 1;
+                    RowPrep ra, rb;
+                    rice_prep(1, ra);
+                    for (int j = 1; j <= kLast; j += 2) {
+                        if (ra.total > (uint32_t)kRowCapBits) { overflow = true; break; }
+                        rice_prep(j < kLast ? j + 1 : kLast, rb);  // (the last row is prepared twice, harmlessly)
+                        rice_put(ra);
+                        pos += ra.total;
                         flush_blocks();
-                        cur = nxt;
+                        if (j == kLast) break;
+                        if (rb.total > (uint32_t)kRowCapBits) { overflow = true; break; }
+                        rice_prep(j + 2 <= kLast ? j + 2 : kLast, ra);
+                        rice_put(rb);
+                        pos += rb.total;
+                        flush_blocks();
                     }
                 }
             } else {
