@@ -107,6 +107,11 @@ def main():
     ap.add_argument("--gather", action="store_true", help="also time the RCCL all-gather-v of the blobs (reported separately)")
     args = ap.parse_args()
 
+    if os.environ.get("FA_BENCH_WATCHDOG_S"):  # rehearsals: dump every thread's stack and exit instead of hanging
+        import faulthandler
+
+        faulthandler.dump_traceback_later(int(os.environ["FA_BENCH_WATCHDOG_S"]), exit=True)
+
     import torch
 
     import flacarray_amd as fa
@@ -168,7 +173,7 @@ def main():
     L.fa_profile_enable(0)
     elapsed = t1 - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

@@ -40,11 +40,14 @@ def gather_stream_nbytes(local_nbytes, n_stream_global, group=None):
     counts = shard_counts(n_stream_global, world)
     maxc = max(counts)
     dev = local_nbytes.device
-    padded = torch.zeros(maxc, dtype=torch.int64, device=dev)
-    padded[: local_nbytes.numel()] = local_nbytes.reshape(-1)
-    gathered = torch.empty(world * maxc, dtype=torch.int64, device=dev)
+    # RCCL moves device tensors; gloo gets the (small) table through the host, also when the data
+    # lives on a GPU (its device-tensor all-gather does not complete when ranks share a device)
+    cdev = dev if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    padded = torch.zeros(maxc, dtype=torch.int64, device=cdev)
+    padded[: local_nbytes.numel()] = local_nbytes.reshape(-1).to(cdev)
+    gathered = torch.empty(world * maxc, dtype=torch.int64, device=cdev)
     dist.all_gather_into_tensor(gathered, padded, group=group)
-    gathered = gathered.reshape(world, maxc)
+    gathered = gathered.reshape(world, maxc).to(dev)
     parts = [gathered[r, : counts[r]] for r in range(world)]
     g_nbytes = torch.cat(parts)
     g_starts = torch.cumsum(g_nbytes, 0) - g_nbytes  # exclusive scan == global_bytes(), mpi.py:181-186
@@ -64,7 +67,11 @@ def all_gather_blobs(local_blob, rank_bytes, group=None):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     offs = np.concatenate([[0], np.cumsum(rank_bytes)]).astype(np.int64)
-    out = torch.empty(int(offs[-1]), dtype=torch.uint8, device=local_blob.device)
+    dev = local_blob.device
+    if world > 1 and dist.get_backend(group) != "nccl" and dev.type != "cpu":
+        # gloo: point-to-point transfers of host tensors
+        return all_gather_blobs(local_blob.cpu(), rank_bytes, group).to(dev)
+    out = torch.empty(int(offs[-1]), dtype=torch.uint8, device=dev)
     out[int(offs[rank]) : int(offs[rank + 1])] = local_blob
     if world == 1:
         return out
