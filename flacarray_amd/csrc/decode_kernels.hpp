@@ -1033,8 +1033,10 @@ __global__ __launch_bounds__(64) FA_K7_WAVES_ATTR void decode_frames_kernel(Deco
             int32_t r = (int32_t)(uu >> 1) ^ -(int32_t)(uu & 1);
             uint32_t nbp = bitpos + (uint32_t)(z + 1 + k);
             double radd = 0.0;  // NCH == 2: what a 33-bit VERBATIM sample adds to its low word
-            if (__builtin_expect(!__all(fastok), 0)) {
-                if (!fastok) {
+            // one compare for both the wave vote and (inside the rare branch only) the lane's own answer
+            const uint64_t okm = __ballot(fastok);
+            if (__builtin_expect(okm != __builtin_amdgcn_read_exec(), 0)) {
+                if (!((okm >> lane) & 1ull)) {
                     if (escw < 0 && z < 32 && ((nbp + 128u) >> kChunkShift) < next_chunk) {
                         // a Rice code of 33..63 bits whose stop bit lies inside the window and whose
                         // successor's window is resident: r and nbp above are already right (the
