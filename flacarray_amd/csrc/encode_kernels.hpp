@@ -1499,6 +1499,13 @@ __global__ __launch_bounds__(256) void write_headers_kernel(uint8_t* __restrict_
 //   tab[1536..2047] xpow[n] = x^(8n) mod P, n < 512
 // ------------------------------------------------------------------------------------------
 constexpr int kCrcTabWords = 2048;  // uint16 entries
+// 256-byte blocks a wave keeps in flight per trip: 32 waves per CU x 2 KB = 64 KB outstanding per CU, what the HBM
+// latency-bandwidth product asks for (tools/ubench/copy_bw.hip: 32 KB per CU in flight copies at 4.7-4.9 TB/s,
+// 64-128 KB at 5.6-5.9 TB/s)
+#ifndef FA_K5_GROUP
+#define FA_K5_GROUP 8
+#endif
+constexpr int kK5Group = FA_K5_GROUP;
 
 __device__ __forceinline__ uint16_t crc_mulmod(uint16_t a, uint16_t b) {
     uint32_t r = 0;
@@ -1536,28 +1543,32 @@ __global__ __launch_bounds__(256) void compact_frames_kernel(const uint8_t* __re
         uint32_t* dstw = reinterpret_cast<uint32_t*>(dst + hcopy);
         const uint32_t sh = hcopy & 3;
         // ---- one pass: CRC-16 over source bytes [0, L) and the copy of every full destination word
-        //      that does not contain a CRC byte; four 256-byte blocks in flight per iteration ----
+        //      that does not contain a CRC byte; kK5Group 256-byte blocks in flight per iteration ----
         const uint32_t NB = (L + 255) >> 8;
         uint16_t t = 0;
         uint32_t last_full = 0;  // number of blocks in which this lane held a full word
         uint16_t partial = 0;
-        for (uint32_t b0 = 0; b0 < NB; b0 += 4) {
-            uint32_t w[4], w1[4];
+        for (uint32_t b0 = 0; b0 < NB; b0 += kK5Group) {
+            uint32_t w[kK5Group], w1[kK5Group];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t wi = 64u * (b0 + i) + (uint32_t)lane;  // source word index (slot has slack)
+            for (int i = 0; i < kK5Group; ++i) {
+                const uint32_t wi = 64u * (b0 + i) + (uint32_t)lane;  // source word index (slots and workspace have slack)
                 w[i] = srcw[wi];
                 w1[i] = srcw[wi + 1];
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < kK5Group; ++i) {
                 const uint32_t b = b0 + i;
                 const uint32_t o = 256u * b + 4u * (uint32_t)lane;
                 if (b < NB) {
                     if (o + 4 <= L) {
+#ifdef FA_K5_NOCRC  // timing experiment only (wrong CRC-16): what the six table lookups per word cost
+                        t = (uint16_t)(t ^ w[i] ^ (w[i] >> 16));
+#else
                         const uint16_t adv = (uint16_t)(tab[1024 + (t >> 8)] ^ tab[1280 + (t & 255)]);
                         const uint16_t c = (uint16_t)(tab[w[i] & 255] ^ tab[256 + ((w[i] >> 8) & 255)] ^ tab[512 + ((w[i] >> 16) & 255)] ^ tab[768 + (w[i] >> 24)]);
                         t = (uint16_t)(adv ^ c);
+#endif
                         last_full = b + 1;
                     } else if (o < L) {
                         uint16_t c = 0;

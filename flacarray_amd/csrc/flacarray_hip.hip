@@ -184,7 +184,7 @@ int make_plan(int64_t n_stream, int64_t stream_size, uint32_t level, EncodePlan*
     pl->off_foff = o;   o = align_up(o + (size_t)pl->F * 8, 256);
     pl->off_snb = o;    o = align_up(o + (size_t)n_stream * 8, 256);
     pl->off_total = o;  o = align_up(o + 8, 256);
-    pl->total = o;
+    pl->total = o + 4096;  // slack: the compaction kernel reads whole groups of 256-byte blocks past a frame's end
     return FA_ERROR_NONE;
 }
 
