@@ -543,7 +543,10 @@ static int encode_device_finish(int nch, int64_t n_stream, int64_t stream_size, 
     hipLaunchKernelGGL(write_headers_kernel, dim3((unsigned)n_stream), dim3(256), 0, st, d_bytes, d_starts, d_foff, pl.nf,
                        stream_size, (int32_t)pl.P.blocksize, (int32_t)pl.tail_bs, (int32_t)nch);
     int64_t nblk = (pl.F + 3) / 4;
-    if (nblk > 8192) nblk = 8192;
+#ifndef FA_K5_MAXBLK
+#define FA_K5_MAXBLK 32768
+#endif
+    if (nblk > FA_K5_MAXBLK) nblk = FA_K5_MAXBLK;
     prof_begin(1, st);
     hipLaunchKernelGGL(compact_frames_kernel, dim3((unsigned)nblk), dim3(256), 0, st,
                        reinterpret_cast<const uint8_t*>(ws + pl.off_slots),
