@@ -27,6 +27,12 @@
 
 namespace fa {
 
+// Translation units (flacarray_amd/build.py): the library is built from two, so that the frame kernels can be
+// compiled with the max-ILP scheduling strategy (K3 -4 %, K7 -2 %) without the compaction kernel, which that
+// strategy slows by 10 %.  FA_UNIT_COMPACT: this header provides only K5 (csrc/compact_unit.hip);
+// FA_SPLIT_UNITS: it provides everything but K5 (csrc/flacarray_hip.hip in the split build); neither: everything.
+#ifndef FA_UNIT_COMPACT
+
 struct FrameInfo {  // optional per-frame decision record (parity debugging)
     int32_t type, order, porder, wasted, shift, precision, nbytes, blocksize;
 };
@@ -1457,6 +1463,13 @@ __global__ __launch_bounds__(1024) void starts_scan_kernel(const int64_t* __rest
     if (tid == 0) *total = (int64_t)carry;
 }
 
+#endif  // !FA_UNIT_COMPACT
+
+#if defined(FA_UNIT_COMPACT) || !defined(FA_SPLIT_UNITS)
+#define FA_HAVE_K5 1
+#endif
+
+#ifdef FA_HAVE_K5
 // ------------------------------------------------------------------------------------------
 // K5a: stream headers.  One 256-thread block per stream.
 // ------------------------------------------------------------------------------------------
@@ -1491,6 +1504,8 @@ __global__ __launch_bounds__(256) void write_headers_kernel(uint8_t* __restrict_
     }
 }
 
+#endif  // FA_HAVE_K5
+
 // ------------------------------------------------------------------------------------------
 // K5b: move every frame from its slot to its final byte offset and fill in its CRC-16.
 // One wavefront per frame, grid-stride; CRC tables (computed on the host once) live in LDS.
@@ -1507,6 +1522,7 @@ constexpr int kCrcTabWords = 2048;  // uint16 entries
 #endif
 constexpr int kK5Group = FA_K5_GROUP;
 
+#ifdef FA_HAVE_K5
 __device__ __forceinline__ uint16_t crc_mulmod(uint16_t a, uint16_t b) {
     uint32_t r = 0;
 #pragma unroll
@@ -1517,7 +1533,8 @@ __device__ __forceinline__ uint16_t crc_mulmod(uint16_t a, uint16_t b) {
     return (uint16_t)r;
 }
 
-__global__ __launch_bounds__(256) void compact_frames_kernel(const uint8_t* __restrict__ slots,
+// (eight waves per SIMD: this kernel lives on memory-level parallelism, whatever the scheduling strategy of the build)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void compact_frames_kernel(const uint8_t* __restrict__ slots,
                                                              const uint32_t* __restrict__ frame_bytes,
                                                              const int64_t* __restrict__ frame_off,
                                                              const int64_t* __restrict__ starts, int64_t nframes,
@@ -1615,5 +1632,37 @@ __global__ __launch_bounds__(256) void compact_frames_kernel(const uint8_t* __re
         (void)nw;
     }
 }
+
+// host-side launchers of the two K5 kernels (defined in the unit that holds the kernels)
+void launch_write_headers(hipStream_t st, int64_t n_stream, uint8_t* out, const int64_t* starts, const int64_t* frame_off,
+                          int64_t nframes, int64_t stream_size, int32_t B, int32_t tail_bs, int32_t nch)
+#if defined(FA_HAVE_K5_LAUNCHERS)
+{
+    hipLaunchKernelGGL(write_headers_kernel, dim3((unsigned)n_stream), dim3(256), 0, st, out, starts, frame_off, nframes,
+                       stream_size, B, tail_bs, nch);
+}
+#else
+;
+#endif
+void launch_compact_frames(hipStream_t st, int64_t nblk, const uint8_t* slots, const uint32_t* frame_bytes,
+                           const int64_t* frame_off, const int64_t* starts, int64_t nframes, int64_t total_frames,
+                           const uint16_t* crc_tab, uint8_t* out, int64_t slot_stride)
+#if defined(FA_HAVE_K5_LAUNCHERS)
+{
+    hipLaunchKernelGGL(compact_frames_kernel, dim3((unsigned)nblk), dim3(256), 0, st, slots, frame_bytes, frame_off, starts,
+                       nframes, total_frames, crc_tab, out, slot_stride);
+}
+#else
+;
+#endif
+#endif  // FA_HAVE_K5 (crc_mulmod, compact_frames_kernel, launchers)
+
+#ifndef FA_HAVE_K5
+void launch_write_headers(hipStream_t st, int64_t n_stream, uint8_t* out, const int64_t* starts, const int64_t* frame_off,
+                          int64_t nframes, int64_t stream_size, int32_t B, int32_t tail_bs, int32_t nch);
+void launch_compact_frames(hipStream_t st, int64_t nblk, const uint8_t* slots, const uint32_t* frame_bytes,
+                           const int64_t* frame_off, const int64_t* starts, int64_t nframes, int64_t total_frames,
+                           const uint16_t* crc_tab, uint8_t* out, int64_t slot_stride);
+#endif
 
 }  // namespace fa

@@ -16,6 +16,9 @@
 
 #include "../../include/flacarray_hip.h"
 #include "decode_kernels.hpp"
+#ifndef FA_SPLIT_UNITS
+#define FA_HAVE_K5_LAUNCHERS 1  // single-unit build: the K5 kernels and their launchers live here
+#endif
 #include "encode_kernels.hpp"
 #include "quantize_kernels.hpp"
 
@@ -540,18 +543,17 @@ static int encode_device_finish(int nch, int64_t n_stream, int64_t stream_size, 
     rc = get_crc_tab(&crc);
     if (rc) return rc;
     const int64_t* d_foff = reinterpret_cast<const int64_t*>(ws + pl.off_foff);
-    hipLaunchKernelGGL(write_headers_kernel, dim3((unsigned)n_stream), dim3(256), 0, st, d_bytes, d_starts, d_foff, pl.nf,
-                       stream_size, (int32_t)pl.P.blocksize, (int32_t)pl.tail_bs, (int32_t)nch);
+    launch_write_headers(st, n_stream, d_bytes, d_starts, d_foff, pl.nf, stream_size, (int32_t)pl.P.blocksize, (int32_t)pl.tail_bs,
+                         (int32_t)nch);
     int64_t nblk = (pl.F + 3) / 4;
 #ifndef FA_K5_MAXBLK
 #define FA_K5_MAXBLK 32768
 #endif
     if (nblk > FA_K5_MAXBLK) nblk = FA_K5_MAXBLK;
     prof_begin(1, st);
-    hipLaunchKernelGGL(compact_frames_kernel, dim3((unsigned)nblk), dim3(256), 0, st,
-                       reinterpret_cast<const uint8_t*>(ws + pl.off_slots),
-                       reinterpret_cast<const uint32_t*>(ws + pl.off_fbytes), d_foff, d_starts, pl.nf, pl.F, crc, d_bytes,
-                       pl.slot_stride);
+    launch_compact_frames(st, nblk, reinterpret_cast<const uint8_t*>(ws + pl.off_slots),
+                          reinterpret_cast<const uint32_t*>(ws + pl.off_fbytes), d_foff, d_starts, pl.nf, pl.F, crc, d_bytes,
+                          pl.slot_stride);
     prof_end(1, st);
     FA_HIP_TRY(hipGetLastError());
     return FA_ERROR_NONE;
