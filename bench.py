@@ -95,6 +95,95 @@ def cpu_baseline(n_samp, seconds_budget=25.0):
     }
 
 
+def make_float_data(torch, n_ch, n_samp, seed, device):
+    """S3 of SURVEY.md 8(d): the same field before rint, float32, amplitude 1 (configuration 3)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = torch.empty((n_ch, n_samp), dtype=torch.float32, device=device)
+    t = torch.arange(n_samp, device=device, dtype=torch.float32)
+    f = 5.0 / n_samp
+    wave = 2.0 * torch.sin(2 * np.pi * 3 * f * t) + 6.0 * torch.sin(2 * np.pi * f * t)
+    for c0 in range(0, n_ch, 64):
+        c1 = min(n_ch, c0 + 64)
+        dc = 5.0 * (torch.rand((c1 - c0, 1), generator=g, device=device) - 0.5)
+        sc = torch.rand((c1 - c0, 1), generator=g, device=device)
+        out[c0:c1] = dc + sc * wave + torch.randn((c1 - c0, n_samp), generator=g, device=device)
+    return out
+
+
+def slice_requests(n_ch, n_samp, n, seed=987654321):
+    """S4 of SURVEY.md 8(d): n scattered (channel, first, length) requests, length 1..8192."""
+    rng = np.random.default_rng(seed)
+    ch = rng.integers(0, n_ch, n)
+    cnt = rng.integers(1, 8193, n)
+    first = (rng.random(n) * (n_samp - cnt + 1)).astype(np.int64)
+    return ch.astype(np.int64), first, cnt.astype(np.int64)
+
+
+def profile_read(L, n=6):
+    ms = (ctypes.c_float * n)()
+    L.fa_profile_read(ms, n)
+    return [float(v) for v in ms]
+
+
+def bench_cfg3(torch, fa, L, n_ch, n_samp, level, dev, steps=3):
+    """Configuration 3 on one GPU: float32 in -> quantise (per-channel quanta) -> encode -> decode with the
+    fused restore -> float32 out.  Reported beside the headline, never as `value`."""
+    from flacarray_amd.libflacarray import EncodeWorkspace
+
+    xf = make_float_data(torch, n_ch, n_samp, 31337, dev)
+    q = (2.0**-16 * (1 + torch.arange(n_ch, device=dev) % 4)).to(torch.float32)
+    ws = EncodeWorkspace()
+
+    def step():
+        ints, off, gain = fa.float32_to_int32_device(xf, q)
+        comp, st, nb = fa.encode_flac_device(ints, level=level, workspace=ws)
+        return fa.decode_flac_device(comp, st, nb, n_samp, offsets=off, gains=gain), comp
+
+    y, comp = step()
+    torch.cuda.synchronize()
+    L.fa_profile_enable(1)
+    k1 = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        y = comp = None
+        y, comp = step()
+        k1.append(profile_read(L)[5])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    L.fa_profile_enable(0)
+    err = float(((y - xf).abs() / (0.5 * q[:, None])).max())  # in units of half a quantum (<= 1 + float32 rounding)
+    return {
+        "workload": f"{n_ch}ch x {n_samp} float32, per-channel quanta 2^-16 (1 + c mod 4), level {level}: quantise, encode, decode + restore",
+        "ms_per_step": round(dt * 1e3, 3),
+        "Msamples_per_s": round(n_ch * n_samp / dt / 1e6, 1),
+        "float32_to_int32_kernel_ms": round(float(np.mean(k1)), 3),
+        "compressed_bytes_per_sample": round(comp.numel() / xf.numel(), 4),
+        "max_abs_err_in_half_quanta": round(err, 4),
+    }
+
+
+def bench_cfg5(torch, fa, comp, st, nb, n_ch, n_samp, x, dev, n_req=10000, reps=5):
+    """Configuration 5 on this rank's store: 10 000 scattered (channel, range) slices in one batched launch,
+    from tensors resident in HBM."""
+    ch, first, cnt = slice_requests(n_ch, n_samp, n_req)
+    out, off = fa.decode_slices_device(comp, st, nb, n_samp, ch, first, cnt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out, off = fa.decode_slices_device(comp, st, nb, n_samp, ch, first, cnt)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    for i in (0, n_req // 2, n_req - 1):  # spot check (the parity tests cover the rest)
+        assert torch.equal(out[off[i] : off[i] + cnt[i]], x[ch[i], first[i] : first[i] + cnt[i]])
+    return {
+        "workload": f"{n_req} scattered (channel, first, length<=8192) slices of the {n_ch}ch x {n_samp} store, one batched launch",
+        "ms_per_batch": round(dt * 1e3, 3),
+        "slices_per_s": round(n_req / dt, 0),
+        "decoded_Msamples_per_s": round(float(cnt.sum()) / dt / 1e6, 1),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,13 +193,21 @@ def main():
     ap.add_argument("--samples", type=int, default=1 << 20)
     ap.add_argument("--level", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather", action="store_true", help="also time the RCCL all-gather-v of the blobs (reported separately)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the configuration 3 / 5 legs (extra keys of the JSON line)")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the all-gather-v of the compressed blobs out of the step")
     args = ap.parse_args()
 
     if os.environ.get("FA_BENCH_WATCHDOG_S"):  # rehearsals: dump every thread's stack and exit instead of hanging
         import faulthandler
 
         faulthandler.dump_traceback_later(int(os.environ["FA_BENCH_WATCHDOG_S"]), exit=True)
+
+    if not args.no_cpu_baseline and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        # the CPU checker is compiled (if stale) before anything touches the GPU: no compiler child process
+        # may start once the HIP runtime -- or a profiler preload -- is live
+        from oracle import oracle as O
+
+        O.build()
 
     import torch
 
@@ -127,10 +224,10 @@ def main():
     dev_index = int(os.environ.get("FA_BENCH_FORCE_DEVICE", local_rank))
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    backend = os.environ.get("FA_BENCH_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist
 
-        backend = os.environ.get("FA_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
@@ -141,6 +238,7 @@ def main():
     x = make_data(torch, n_ch, n_samp, 123456789 + rank, dev)
     ws = EncodeWorkspace()
     n_global = n_ch * world
+    gather_state = {"on": world > 1 and not args.no_gather, "error": None, "bytes": 0}
 
     def sync():
         if world > 1:
@@ -150,8 +248,20 @@ def main():
     def step():
         comp, st, nb = fa.encode_flac_device(x, level=args.level, workspace=ws)
         if world > 1:
-            # global stream_starts: all-gather of the per-stream byte counts + exclusive scan
-            fdist.gather_stream_nbytes(nb.reshape(-1), n_global)
+            # Configuration 4: the global (compressed, stream_starts, stream_nbytes) triple on every GPU --
+            # all-gather of the per-stream byte counts + exclusive scan (global_bytes, mpi.py:156-187), then the
+            # all-gather-v of the shard blobs over xGMI (one batched round of point-to-point transfers).  A failure
+            # of the never-before-run RCCL leg is recorded and the remaining steps run without it.
+            if gather_state["on"]:
+                try:
+                    g_blob, _, _ = fdist.assemble_global(comp, nb.reshape(-1), n_global)
+                    gather_state["bytes"] = int(g_blob.numel())
+                    del g_blob
+                except Exception as e:  # noqa: BLE001
+                    gather_state["on"] = False
+                    gather_state["error"] = f"{type(e).__name__}: {e}"[:300]
+            if not gather_state["on"]:
+                fdist.gather_stream_nbytes(nb.reshape(-1), n_global)
         y = fa.decode_flac_device(comp, st, nb, n_samp)
         return comp, st, nb, y
 
@@ -159,15 +269,13 @@ def main():
         step()
     sync()
     L.fa_profile_enable(1)
-    enc_ms, cmp_ms, dec_ms = [], [], []
+    prof = []
     t0 = time.perf_counter()
     comp = st = nb = y = None
     for _ in range(args.steps):
         comp = st = nb = y = None  # hand the previous outputs back to the caching allocator (no hipMalloc in the timed region)
         comp, st, nb, y = step()
-        ms = (ctypes.c_float * 3)()
-        L.fa_profile_last(ms)
-        enc_ms.append(ms[0]); cmp_ms.append(ms[1]); dec_ms.append(ms[2])
+        prof.append(profile_read(L))
     sync()
     t1 = time.perf_counter()
     L.fa_profile_enable(0)
@@ -181,24 +289,36 @@ def main():
     assert torch.equal(y, x), "decode(encode(x)) != x"
     c_bytes = comp.numel() / x.numel()
 
-    gather_s = None
-    if args.gather and world > 1:
-        sync()
-        g0 = time.perf_counter()
-        fdist.assemble_global(comp, nb.reshape(-1), n_global)
-        sync()
-        gather_s = time.perf_counter() - g0
+    cfg5 = cfg3 = None
+    if not args.no_extra:
+        if world > 1:
+            # configuration 5 on the sharded store: every request goes to the GPU that owns its channel
+            store_req = slice_requests(n_global, n_samp, 10000)
+            own = fdist.owner_of(store_req[0], n_global, world) == rank
+            lo = fdist.shard_range(n_global, world, rank)[0]
+            sync()
+            g0 = time.perf_counter()
+            fa.decode_slices_device(comp, st, nb, n_samp, store_req[0][own] - lo, store_req[1][own], store_req[2][own])
+            sync()
+            cfg5 = {"workload": f"10000 scattered slices of the {n_global}ch store, routed to the owning GPU (dist.route_slices rule)",
+                    "ms_per_batch": round((time.perf_counter() - g0) * 1e3, 3)}
+            cfg5["slices_per_s"] = round(10000 / (cfg5["ms_per_batch"] * 1e-3), 0)
+        elif rank == 0:
+            cfg5 = bench_cfg5(torch, fa, comp, st, nb, n_ch, n_samp, x, dev)
 
     if rank == 0:
         samples_per_step = n_ch * n_samp * world
         ms_per_step = elapsed / args.steps * 1e3
         value = samples_per_step / (elapsed / args.steps) / 1e6
-        enc = float(np.mean(enc_ms)); dec = float(np.mean(dec_ms)); cmpm = float(np.mean(cmp_ms))
+        pm = np.mean(np.array(prof), axis=0)
+        enc, cmpm, dec, enc_seq, dec_seq = (float(v) for v in pm[:5])
         n_local = n_ch * n_samp
+        alg_gb = (4 + c_bytes) * n_local / 1e9  # algorithmic bytes of one direction: 4 + c per sample
+        gbs = lambda ms: round(alg_gb / (ms * 1e-3), 1) if ms > 0 else None  # noqa: E731
         kernels = {
-            "encode_frames_kernel": {"ms": round(enc, 3), "algorithmic_GBs": round((4 + c_bytes) * n_local / (enc * 1e-3) / 1e9, 1)},
-            "compact_frames_kernel": {"ms": round(cmpm, 3), "algorithmic_GBs": round(2 * c_bytes * n_local / (cmpm * 1e-3) / 1e9, 1)},
-            "decode_frames_kernel": {"ms": round(dec, 3), "algorithmic_GBs": round((4 + c_bytes) * n_local / (dec * 1e-3) / 1e9, 1)},
+            "encode_frames_kernel": {"ms": round(enc, 3), "algorithmic_GBs": gbs(enc)},
+            "compact_frames_kernel": {"ms": round(cmpm, 3), "algorithmic_GBs": round(2 * c_bytes * n_local / (cmpm * 1e-3) / 1e9, 1) if cmpm > 0 else None},
+            "decode_frames_kernel": {"ms": round(dec, 3), "algorithmic_GBs": gbs(dec)},
         }
         dom = max(("encode_frames_kernel", "decode_frames_kernel"), key=lambda k: kernels[k]["ms"])
         achieved = kernels[dom]["algorithmic_GBs"]
@@ -221,28 +341,46 @@ def main():
                 "samples_per_channel": n_samp,
                 "level": args.level,
                 "compressed_bytes_per_sample": round(c_bytes, 4),
-                "parallelism": f"channels sharded over {world} GPU(s), no data-path collective",
+                "parallelism": (f"channels sharded over {world} GPU(s), no data-path collective"
+                                + ("" if world == 1 else ("; per step: all-gather of stream byte counts"
+                                                          + (" + all-gather-v of the compressed blobs (global triple on every GPU)" if gather_state["on"] else "")))),
             },
             "roofline": {
                 "bound": "hbm",
                 "kernel": dom,
                 "achieved": achieved,
-                "algorithmic_GB_per_launch": round((4 + c_bytes) * n_local / 1e9, 3),
+                "algorithmic_GB_per_launch": round(alg_gb, 3),
                 "ms_per_launch": kernels[dom]["ms"],
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": measured_traffic(dom) if (n_ch, n_samp) == (4096, 1 << 20) else None,
-                "traffic_unit": "GB per launch (PMC, profiles/r*_traffic.json)",
+                "traffic_unit": "GB per launch; constant from the newest committed PMC pass (profiles/r*_traffic.json), not measured in this run",
                 "algorithmic_bytes_per_sample": round(4 + c_bytes, 4),
+                # what actually limits the kernel (profiles/*_pmc_sq_insts.csv): instruction issue, not HBM
+                "limiter": "valu_issue",
+                # the unit is the whole sequence -- HIP events around begin..finish (K3+K4+K5, host gaps
+                # included) and around K6+K7, on the launch stream
+                "encode_sequence": {"ms": round(enc_seq, 3), "achieved": gbs(enc_seq), "frac": round(gbs(enc_seq) / HBM_PEAK_GBS, 4) if enc_seq > 0 else None},
+                "decode_sequence": {"ms": round(dec_seq, 3), "achieved": gbs(dec_seq), "frac": round(gbs(dec_seq) / HBM_PEAK_GBS, 4) if dec_seq > 0 else None},
             },
             "kernels": kernels,
-            # each direction on its own (kernel time of K3+K5 / of K7, HIP events on the launch stream)
-            "encode_Msamples_per_s": round(n_local * world / ((enc + cmpm) * 1e-3) / 1e6, 1),
-            "decode_Msamples_per_s": round(n_local * world / (dec * 1e-3) / 1e6, 1),
+            # each direction on its own (sequence time, HIP events on the launch stream)
+            "encode_Msamples_per_s": round(n_local * world / (enc_seq * 1e-3) / 1e6, 1) if enc_seq > 0 else None,
+            "decode_Msamples_per_s": round(n_local * world / (dec_seq * 1e-3) / 1e6, 1) if dec_seq > 0 else None,
         }
-        if gather_s is not None:
-            out["allgatherv_s"] = round(gather_s, 4)
+        if world > 1:
+            out["allgatherv"] = {"in_step": bool(gather_state["on"]), "global_blob_bytes": gather_state["bytes"], "error": gather_state["error"]}
+        if cfg5 is not None:
+            out["cfg5"] = cfg5
+    if not args.no_extra and world == 1:
+        # configuration 3 needs the HBM the headline's tensors hold
+        x = y = comp = st = nb = ws = None
+        torch.cuda.empty_cache()
+        L.fa_release_scratch()
+        cfg3 = bench_cfg3(torch, fa, L, n_ch, n_samp, args.level, dev)
+        out["cfg3"] = cfg3
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(n_samp)
         print(json.dumps(out))

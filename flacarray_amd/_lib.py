@@ -37,6 +37,7 @@ SYMBOLS = [
     "fa_int32_to_float32_device",
     "fa_profile_enable",
     "fa_profile_last",
+    "fa_profile_read",
     "fa_release_scratch",
     "fa_device_count",
     "fa_version",
@@ -98,6 +99,8 @@ def lib():
     L.fa_profile_enable.restype = None
     L.fa_profile_last.argtypes = [ctypes.POINTER(ctypes.c_float)]
     L.fa_profile_last.restype = cint
+    L.fa_profile_read.argtypes = [ctypes.POINTER(ctypes.c_float), cint]
+    L.fa_profile_read.restype = cint
     L.fa_release_scratch.argtypes = []
     L.fa_release_scratch.restype = None
     L.fa_device_count.argtypes = []

@@ -47,7 +47,7 @@ class FlacArray:
             self._stream_offsets = copy.deepcopy(other._stream_offsets)
             self._stream_gains = copy.deepcopy(other._stream_gains)
             self._mpi_dist = copy.deepcopy(other._mpi_dist)
-            self._mpi_comm = other._mpi_comm
+            self._mpi_comm = other._mpi_comm  # (a copy starts without the HBM mirror of `other`)
         else:
             self._shape = tuple(shape)
             if global_shape is not None:
@@ -64,6 +64,7 @@ class FlacArray:
             self._mpi_dist = mpi_dist
         if self._mpi_comm is not None:
             raise NotImplementedError("mpi4py communicators are not supported; see flacarray_amd.dist for multi-GPU sharding")
+        self._resident = None  # device copies of (compressed, starts, nbytes, offsets, gains): see to_device()
         self._init_params()
 
     def _init_params(self):
@@ -240,11 +241,76 @@ class FlacArray:
                 keep[tuple(lead_key)] = True
         return tuple(lead_shape) + samp_shape, keep, first, last
 
+    # ---- HBM residency (addition to the reference API) ----
+    def to_device(self, device=None):
+        """Keep the compressed store resident in HBM: bytes, starts, nbytes (and offsets / gains) are uploaded
+        once; `__getitem__`, `to_array` and `read_slices` then decode straight from those tensors and only the
+        decoded samples cross PCIe.  The reference's usage pattern is many small reads from one store
+        (array.py:409-449: one decode call per key); without residency every read re-uploads its byte span.
+        Returns self."""
+        import torch
+
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        flat = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt).reshape(-1)).to(dev)  # noqa: E731
+        res = {
+            "device": dev,
+            "compressed": torch.from_numpy(np.ascontiguousarray(self._compressed)).to(dev),
+            "starts": flat(self._stream_starts, np.int64),
+            "nbytes": flat(self._stream_nbytes, np.int64),
+            "offsets": None,
+            "gains": None,
+        }
+        if self._stream_offsets is not None:
+            ft = np.float64 if self._is_int64 else np.float32
+            res["offsets"] = flat(self._stream_offsets, ft)
+            res["gains"] = flat(self._stream_gains, ft)
+        self._resident = res
+        return self
+
+    def release_device(self):
+        """Drop the HBM copy made by to_device()."""
+        self._resident = None
+        return self
+
+    @property
+    def is_resident(self):
+        return self._resident is not None
+
+    def _decode_resident(self, keep, first, last, as_tensor=False):
+        """Decode [first, last) (negative: everything) of the kept streams from the resident store.
+        Returns (2-D result: kept streams x samples, list of kept multi-indices or None)."""
+        import torch
+
+        from .libflacarray import decode_flac_device
+
+        res = self._resident
+        indices = None
+        st, nb, off, gain = res["starts"], res["nbytes"], res["offsets"], res["gains"]
+        if keep is not None:
+            if keep.shape != tuple(self._leading_shape):
+                raise RuntimeError("The keep array should have the same shape as stream_starts")
+            sel = np.flatnonzero(np.asarray(keep).reshape(-1))
+            indices = list(zip(*(ax.tolist() for ax in np.unravel_index(sel, self._leading_shape))))
+            idx = torch.from_numpy(sel).to(res["device"])
+            st, nb = st[idx].contiguous(), nb[idx].contiguous()
+            if off is not None:
+                off, gain = off[idx].contiguous(), gain[idx].contiguous()
+        if st.numel() == 0:
+            n = self._stream_size if (first < 0 or last < 0) else last - first
+            out = torch.zeros((0, n), dtype=getattr(torch, self._typestr), device=res["device"])
+        else:
+            out = decode_flac_device(res["compressed"], st, nb, self._stream_size, first, last, offsets=off, gains=gain,
+                                     is_int64=self._is_int64)
+        return (out if as_tensor else out.cpu().numpy()), indices
+
     def __getitem__(self, raw_key):
         """Decompress a selection on the fly; the result has numpy's shape for the same key."""
         shape, keep, first, last = self._plan_selection(raw_key)
         if 0 in shape:
             return np.zeros(shape, dtype=self._dtype)
+        if self._resident is not None:
+            arr, _ = self._decode_resident(keep, first, last)
+            return arr.reshape(shape)
         arr, _ = array_decompress_slice(
             self._compressed, self._stream_size, self._stream_starts, self._stream_nbytes, stream_offsets=self._stream_offsets,
             stream_gains=self._stream_gains, keep=keep, first_stream_sample=first, last_stream_sample=last,
@@ -290,6 +356,16 @@ class FlacArray:
             if stream_slice.step is not None and stream_slice.step != 1:
                 raise RuntimeError("Only stream slices with a step size of 1 are supported")
             first_samp, last_samp, _ = stream_slice.indices(self._stream_size)
+        if self._resident is not None:
+            f, l = (-1, -1) if first_samp is None else (first_samp, last_samp)
+            if f >= 0 and l <= f:
+                raise RuntimeError("first_sample is larger than last_sample")
+            arr, indices = self._decode_resident(keep, f, l)
+            if keep is None:
+                arr = arr.reshape(self._shape[:-1] + (arr.shape[-1],)) if not self._flatten_single else arr.reshape(-1)
+            if keep is not None and keep_indices:
+                return (arr, indices)
+            return arr
         arr, indices = array_decompress_slice(
             self._compressed,
             self._stream_size,
@@ -308,30 +384,77 @@ class FlacArray:
             return (arr, indices)
         return arr
 
-    def read_slices(self, streams, first, count):
+    def read_slices(self, streams, first, count, as_tensor=False):
         """Batched random access (addition to the reference API).
 
         streams: flat (C-order) stream indices; first/count: sample ranges.  Returns a list of
-        1-D arrays, one per request, decoded with ONE kernel launch on the GPU.
+        1-D arrays, one per request, decoded with ONE kernel launch on the GPU (as_tensor: the flat
+        device tensor and the int64 array of its per-request offsets instead).  On a store made
+        resident with to_device() nothing but the request table is uploaded.
         """
         import torch
 
         from .libflacarray import decode_slices_device
 
-        dev = torch.device("cuda", torch.cuda.current_device())
-        comp = torch.from_numpy(np.ascontiguousarray(self._compressed)).to(dev)
-        st = torch.from_numpy(np.ascontiguousarray(self._stream_starts).reshape(-1)).to(dev)
-        nb = torch.from_numpy(np.ascontiguousarray(self._stream_nbytes).reshape(-1)).to(dev)
-        off = gain = None
-        if self._stream_offsets is not None:
-            off = torch.from_numpy(np.ascontiguousarray(self._stream_offsets).reshape(-1))
-            gain = torch.from_numpy(np.ascontiguousarray(self._stream_gains).reshape(-1))
+        res = self._resident
+        if res is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+            comp = torch.from_numpy(np.ascontiguousarray(self._compressed)).to(dev)
+            st = torch.from_numpy(np.ascontiguousarray(self._stream_starts).reshape(-1)).to(dev)
+            nb = torch.from_numpy(np.ascontiguousarray(self._stream_nbytes).reshape(-1)).to(dev)
+            off = gain = None
+            if self._stream_offsets is not None:
+                off = torch.from_numpy(np.ascontiguousarray(self._stream_offsets).reshape(-1))
+                gain = torch.from_numpy(np.ascontiguousarray(self._stream_gains).reshape(-1))
+        else:
+            comp, st, nb, off, gain = res["compressed"], res["starts"], res["nbytes"], res["offsets"], res["gains"]
         out, out_off = decode_slices_device(
             comp, st, nb, self._stream_size, streams, first, count, offsets=off, gains=gain, is_int64=self._is_int64
         )
+        if as_tensor:
+            return out, out_off
         flat = out.cpu().numpy()
         count = np.asarray(count, dtype=np.int64)
         return [flat[o : o + c] for o, c in zip(out_off, count)]
+
+    @classmethod
+    def from_device_array(cls, data, level=5, quanta=None):
+        """Construct a RESIDENT FlacArray from a torch tensor that already lives in HBM (int32 / int64, or
+        float32 with per-stream `quanta`): quantise + encode on the device, keep the store there, and mirror
+        it to host arrays so that every property of the reference API still answers with numpy."""
+        import torch
+
+        from .libflacarray import encode_flac_device, float32_to_int32_device
+
+        offsets = gains = None
+        ints = data
+        if data.dtype == torch.float32:
+            if quanta is None:
+                raise RuntimeError("Compressing floating point data ('float32') requires specifying either quanta or precision.")
+            lead = tuple(data.shape[:-1]) if data.dim() > 1 else (1,)
+            q = torch.as_tensor(quanta, dtype=torch.float32, device=data.device)
+            q = q.expand(lead).contiguous() if q.dim() == 0 else q
+            ints, offsets, gains = float32_to_int32_device(data.contiguous(), q)
+        elif data.dtype not in (torch.int32, torch.int64):
+            raise ValueError(f"Unsupported data type '{data.dtype}'")
+        comp, st, nb = encode_flac_device(ints.contiguous(), level=level)
+        shape = tuple(data.shape)
+        out = FlacArray(
+            None,
+            shape=shape,
+            global_shape=(1, shape[0]) if len(shape) == 1 else shape,
+            compressed=comp.cpu().numpy(),
+            dtype=np.dtype(str(data.dtype).replace("torch.", "")),
+            stream_starts=st.cpu().numpy(),
+            stream_nbytes=nb.cpu().numpy(),
+            stream_offsets=None if offsets is None else offsets.cpu().numpy(),
+            stream_gains=None if gains is None else gains.cpu().numpy(),
+        )
+        out._resident = {
+            "device": data.device, "compressed": comp, "starts": st.reshape(-1), "nbytes": nb.reshape(-1),
+            "offsets": None if offsets is None else offsets.reshape(-1), "gains": None if gains is None else gains.reshape(-1),
+        }
+        return out
 
     @classmethod
     def from_array(cls, arr, level=5, quanta=None, precision=None, mpi_comm=None, use_threads=False):

@@ -46,14 +46,17 @@ def build(force=False, verbose=False):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cflags = [f for f in FLAGS if f != "-shared"]
-    objs = []
-    for src, extra in ((SRC, MAIN_UNIT_FLAGS), (SRC_COMPACT, [])):
+    objs, procs = [], []
+    for src, extra in ((SRC, MAIN_UNIT_FLAGS), (SRC_COMPACT, [])):  # the two units compile side by side
         obj = os.path.join(os.path.dirname(OUT), os.path.basename(src).replace(".hip", ".o"))
         cmd = [hipcc] + cflags + extra + ["-c", "-o", obj, src]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
+        procs.append((cmd, subprocess.Popen(cmd)))
         objs.append(obj)
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
     cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", OUT + ".tmp"] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

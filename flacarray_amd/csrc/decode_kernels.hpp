@@ -54,14 +54,23 @@ __device__ __forceinline__ uint64_t load_be64(const uint8_t* p) {
 
 __global__ __launch_bounds__(256) void parse_streams_kernel(const uint8_t* __restrict__ blob, const int64_t* __restrict__ starts,
                                                             const int64_t* __restrict__ nbytes, int64_t n_stream,
-                                                            int64_t stream_size, StreamMeta* __restrict__ meta,
-                                                            int* __restrict__ err) {
+                                                            int64_t stream_size, int64_t blob_bytes,
+                                                            StreamMeta* __restrict__ meta, int* __restrict__ err) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= n_stream) return;
-    const uint8_t* p = blob + starts[s];
+    const int64_t st0 = starts[s];
     const int64_t nb = nbytes[s];
     StreamMeta m;
-    m.first_frame = -1; m.seek_abs = -1; m.end_abs = starts[s] + nb; m.npoints = 0; m.B = 0; m.bps = 0; m.flags = 0; m.channels = 0;
+    m.first_frame = -1; m.seek_abs = -1; m.end_abs = 0; m.npoints = 0; m.B = 0; m.bps = 0; m.flags = 0; m.channels = 0;
+    // a damaged index (negative or out-of-range starts / nbytes, e.g. from a corrupt stream_starts dataset) must not
+    // become an out-of-range read: nothing of the stream is touched before this test
+    if (st0 < 0 || nb < 0 || st0 > blob_bytes || nb > blob_bytes - st0) {
+        atomicOr(err, kErrDecodeInit);
+        meta[s] = m;
+        return;
+    }
+    const uint8_t* p = blob + st0;
+    m.end_abs = st0 + nb;
     bool ok = nb >= 42 && p[0] == 'f' && p[1] == 'L' && p[2] == 'a' && p[3] == 'C';
     int64_t off = 4;
     while (ok) {

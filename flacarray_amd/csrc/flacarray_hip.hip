@@ -10,7 +10,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -35,55 +37,84 @@ using namespace fa;
         }                                                                                         \
     } while (0)
 
-std::mutex g_mu;            // device-state caches (windows, CRC table, scratch slots)
-std::recursive_mutex g_api_mu;  // one compute call at a time: the calls share the cached scratch buffers
-#define FA_API_LOCK std::lock_guard<std::recursive_mutex> api_lock_(g_api_mu)
-
-// optional in-library kernel timing (HIP events on the launch stream), see fa_profile_enable
-bool g_prof = false;
-hipEvent_t g_ev[6];
-bool g_ev_ready = false;
-bool g_ev_set[3] = {false, false, false};
-
-void prof_begin(int k, hipStream_t st) {
-    if (!g_prof) return;
-    if (!g_ev_ready) {
-        for (auto& e : g_ev) (void)hipEventCreate(&e);
-        g_ev_ready = true;
-    }
-    (void)hipEventRecord(g_ev[2 * k], st);
-}
-void prof_end(int k, hipStream_t st) {
-    if (!g_prof) return;
-    (void)hipEventRecord(g_ev[2 * k + 1], st);
-    g_ev_set[k] = true;
-}
-
+// Per-device state.  Every compute entry point runs under the api_mu of the CURRENT device (the calls of one
+// device share its cached scratch buffers); calls that target different devices -- one process driving several
+// GPUs from several threads -- do not serialise each other.  g_mu guards the map of device states only.
+constexpr int kProfPairs = 6;
 struct DeviceState {
+    std::recursive_mutex api_mu;
     std::map<int, float*> windows;  // blocksize -> device tukey(0.5) table
     uint16_t* crc_tab = nullptr;
     void* scratch[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t scratch_epoch = 1;  // bumped whenever a scratch slot is (re)allocated or released: cached contents are then stale
+    // frame-header table of the most recent encode geometry (host copy + what the device copy was built from)
+    std::vector<uint4> h_hdr;
+    int64_t c_nf = -1;
+    int c_B = 0, c_tail = 0, c_nch = 0;
+    void* c_dp = nullptr;
+    uint64_t c_epoch = 0;
+    bool stamps_zeroed = false;
+    // optional in-library kernel timing (HIP events on the launch stream), see fa_profile_enable
+    // pairs: 0 K3 encode_frames, 1 K5 compact_frames, 2 K7 decode_frames, 3 whole encode sequence (begin .. finish),
+    // 4 whole decode sequence (K6 + K7 + checks), 5 K1 float32_to_int32
+    hipEvent_t ev[2 * kProfPairs];
+    bool ev_ready = false;
+    bool ev_set[kProfPairs] = {false, false, false, false, false, false};
 };
-std::map<int, DeviceState> g_dev;
-uint64_t g_scratch_epoch = 1;  // bumped whenever a scratch slot is (re)allocated or released: cached contents are then stale
+std::mutex g_mu;
+std::map<int, std::unique_ptr<DeviceState>> g_dev;
+std::atomic<bool> g_prof{false};
 
 DeviceState* dev_state() {
     int d = 0;
     if (hipGetDevice(&d) != hipSuccess) return nullptr;
-    return &g_dev[d];
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto& p = g_dev[d];
+    if (!p) p.reset(new DeviceState());
+    return p.get();
+}
+#define FA_API_LOCK_OR(fail_stmt)      \
+    DeviceState* ds_ = dev_state();    \
+    if (!ds_) { fail_stmt; }           \
+    std::lock_guard<std::recursive_mutex> api_lock_(ds_->api_mu)
+#define FA_API_LOCK FA_API_LOCK_OR(return FA_ERROR_DEVICE)
+
+// the reference's restore functions return void (flacarray.h:295-311): a device failure cannot be reported to the
+// caller, and returning garbage silently is worse than stopping -- say which call failed, then abort
+[[noreturn]] void fatal_device(const char* fn, const char* what) {
+    std::fprintf(stderr, "flacarray_hip: %s: %s failed (%s); this entry point has no error channel and no CPU fallback\n", fn, what,
+                 hipGetErrorString(hipGetLastError()));
+    std::abort();
 }
 
-// grow-only cached device scratch; slot selects independent buffers
+void prof_begin(int k, hipStream_t st) {
+    if (!g_prof) return;
+    DeviceState* ds = dev_state();
+    if (!ds) return;
+    if (!ds->ev_ready) {
+        for (auto& e : ds->ev) (void)hipEventCreate(&e);
+        ds->ev_ready = true;
+    }
+    (void)hipEventRecord(ds->ev[2 * k], st);
+}
+void prof_end(int k, hipStream_t st) {
+    if (!g_prof) return;
+    DeviceState* ds = dev_state();
+    if (!ds) return;
+    (void)hipEventRecord(ds->ev[2 * k + 1], st);
+    ds->ev_set[k] = true;
+}
+
+// grow-only cached device scratch of the current device; slot selects independent buffers (callers hold api_mu)
 int get_scratch(int slot, size_t bytes, void** out) {
-    std::lock_guard<std::mutex> lk(g_mu);
     DeviceState* st = dev_state();
     if (!st) return FA_ERROR_DEVICE;
     if (st->scratch_bytes[slot] < bytes) {
         if (st->scratch[slot]) (void)hipFree(st->scratch[slot]);
         st->scratch[slot] = nullptr;
         st->scratch_bytes[slot] = 0;
-        g_scratch_epoch++;
+        st->scratch_epoch++;
         size_t want = bytes + (bytes >> 3) + 256;
         if (hipMalloc(&st->scratch[slot], want) != hipSuccess) {
             if (hipMalloc(&st->scratch[slot], bytes) != hipSuccess) return FA_ERROR_ALLOC | FA_ERROR_DEVICE;
@@ -108,7 +139,6 @@ void tukey_window(int L, std::vector<float>& w) {
 }
 
 int get_window(int L, const float** out) {
-    std::lock_guard<std::mutex> lk(g_mu);
     DeviceState* st = dev_state();
     if (!st) return FA_ERROR_DEVICE;
     auto it = st->windows.find(L);
@@ -127,7 +157,6 @@ int get_window(int L, const float** out) {
 
 // CRC-16 (poly 0x8005) tables for compact_frames_kernel, see encode_kernels.hpp
 int get_crc_tab(const uint16_t** out) {
-    std::lock_guard<std::mutex> lk(g_mu);
     DeviceState* st = dev_state();
     if (!st) return FA_ERROR_DEVICE;
     if (!st->crc_tab) {
@@ -211,6 +240,7 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
         d_bytes = reinterpret_cast<const unsigned char*>(al);
     }
     // ---- K6: parse stream headers ----
+    prof_begin(4, st);
     void* p = nullptr;
     const size_t meta_bytes = align_up((size_t)n_stream * sizeof(StreamMeta), 256);
     int rc = get_scratch(1, meta_bytes + 256 + (size_t)n_stream * 4, &p);
@@ -221,7 +251,7 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
     int* d_sflag = d_err + 64;  // per stream: 1 = sync scan ambiguous, walk serially
     FA_HIP_TRY(hipMemsetAsync(d_err, 0, 16, st));
     hipLaunchKernelGGL(parse_streams_kernel, dim3((unsigned)((n_stream + 255) / 256)), dim3(256), 0, st, d_bytes, d_starts,
-                       d_nbytes, n_stream, stream_size, d_meta, d_err);
+                       d_nbytes, n_stream, stream_size, n_bytes, d_meta, d_err);
     StreamMeta m0;
     int h_err[4] = {0, 0, 0, 0};
     FA_HIP_TRY(hipMemcpyAsync(&m0, d_meta, sizeof(StreamMeta), hipMemcpyDeviceToHost, st));
@@ -338,6 +368,7 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
     if (f32) hipLaunchKernelGGL((decode_frames_kernel<8, -1, true, 1>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
     else hipLaunchKernelGGL((decode_frames_kernel<8, -1, false, 1>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
     prof_end(2, st);
+    prof_end(4, st);  // (deeper-history passes, when a stream needs them, follow outside this pair)
     FA_HIP_TRY(hipMemcpyAsync(h_err, d_err, 16, hipMemcpyDeviceToHost, st));
     FA_HIP_TRY(hipStreamSynchronize(st));
     if (h_err[1] & kFlagNeed16) {
@@ -375,10 +406,13 @@ extern "C" {
 
 const char* fa_version(void) { return "flacarray_hip 0.1.0 (gfx950)"; }
 
-void fa_profile_enable(int on) { g_prof = (on != 0); }
+void fa_profile_enable(int on) { g_prof = (on != 0); }  // process-wide switch; the events are per device
 
-// diagnostic build only: read (and optionally clear) the per-phase cycle sums of K3
+#ifdef FA_STAMPS
+// diagnostic build only (-DFA_STAMPS, flacarray_amd/build.py --stamps): read (and optionally clear) the per-phase
+// cycle sums of K3.  Not part of the shipped ABI.
 int fa_debug_stamps(unsigned long long* out32, int reset) {
+    FA_API_LOCK;
     void* sp = nullptr;
     if (get_scratch(6, 256, &sp)) return FA_ERROR_DEVICE;
     if (hipDeviceSynchronize() != hipSuccess) return FA_ERROR_DEVICE;
@@ -386,18 +420,22 @@ int fa_debug_stamps(unsigned long long* out32, int reset) {
     if (reset && hipMemset(sp, 0, 256) != hipSuccess) return FA_ERROR_DEVICE;
     return FA_ERROR_NONE;
 }
+#endif
 
-int fa_profile_last(float* ms3) {
-    for (int k = 0; k < 3; ++k) {
-        ms3[k] = -1.0f;
-        if (g_ev_ready && g_ev_set[k]) {
-            if (hipEventSynchronize(g_ev[2 * k + 1]) != hipSuccess) return FA_ERROR_DEVICE;
+int fa_profile_read(float* ms, int n) {
+    FA_API_LOCK;
+    for (int k = 0; k < n; ++k) {
+        ms[k] = -1.0f;
+        if (k < kProfPairs && ds_->ev_ready && ds_->ev_set[k]) {
+            if (hipEventSynchronize(ds_->ev[2 * k + 1]) != hipSuccess) return FA_ERROR_DEVICE;
             float t = 0.0f;
-            if (hipEventElapsedTime(&t, g_ev[2 * k], g_ev[2 * k + 1]) == hipSuccess) ms3[k] = t;
+            if (hipEventElapsedTime(&t, ds_->ev[2 * k], ds_->ev[2 * k + 1]) == hipSuccess) ms[k] = t;
         }
     }
     return FA_ERROR_NONE;
 }
+
+int fa_profile_last(float* ms3) { return fa_profile_read(ms3, 3); }
 
 int fa_device_count(void) {
     int n = 0;
@@ -406,15 +444,13 @@ int fa_device_count(void) {
 }
 
 void fa_release_scratch(void) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    DeviceState* st = dev_state();
-    if (!st) return;
+    FA_API_LOCK_OR(return);
     for (int i = 0; i < 12; ++i) {
-        if (st->scratch[i]) (void)hipFree(st->scratch[i]);
-        st->scratch[i] = nullptr;
-        st->scratch_bytes[i] = 0;
+        if (ds_->scratch[i]) (void)hipFree(ds_->scratch[i]);
+        ds_->scratch[i] = nullptr;
+        ds_->scratch_bytes[i] = 0;
     }
-    g_scratch_epoch++;
+    ds_->scratch_epoch++;
 }
 
 int64_t fa_encode_workspace_bytes(int64_t n_stream, int64_t stream_size, uint32_t level) {
@@ -439,6 +475,7 @@ static int encode_device_begin(const int32_t* d_data, int nch, int64_t n_stream,
     if (!d_workspace || workspace_bytes < (int64_t)pl.total) return FA_ERROR_ALLOC;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     char* ws = reinterpret_cast<char*>(d_workspace);
+    prof_begin(3, st);
     EncodeArgs a;
     a.data = d_data; a.n_stream = n_stream; a.stream_size = stream_size; a.nframes = pl.nf;
     a.B = pl.P.blocksize; a.tail_bs = pl.tail_bs;
@@ -457,33 +494,26 @@ static int encode_device_begin(const int32_t* d_data, int nch, int64_t n_stream,
     a.escale_full = 0.5 / (double)a.B;
     a.escale_tail = 0.5 / (double)a.tail_bs;
     {
-        // frame header fields by frame number: tabulated on the host, cached on the device
-        static std::vector<uint4> h_hdr;
-        static int64_t c_nf = -1;
-        static int c_B = 0, c_tail = 0, c_nch = 0, c_dev = -1;
-        static void* c_dp = nullptr;
-        static uint64_t c_epoch = 0;
-        int dev = 0;
-        FA_HIP_TRY(hipGetDevice(&dev));
+        // frame header fields by frame number: tabulated on the host, cached on the device (per-device state)
         void* dp = nullptr;
         rc = get_scratch(9, (size_t)pl.nf * sizeof(uint4) + 256, &dp);
         if (rc) return rc;
-        if (c_nf != pl.nf || c_B != a.B || c_tail != a.tail_bs || c_nch != nch || c_dev != dev || c_dp != dp || c_epoch != g_scratch_epoch) {
-            h_hdr.resize((size_t)pl.nf);
+        if (ds_->c_nf != pl.nf || ds_->c_B != a.B || ds_->c_tail != a.tail_bs || ds_->c_nch != nch || ds_->c_dp != dp ||
+            ds_->c_epoch != ds_->scratch_epoch) {
+            ds_->h_hdr.resize((size_t)pl.nf);
             for (int64_t f = 0; f < pl.nf; ++f)
-                h_hdr[(size_t)f] = frame_header_entry((uint64_t)f, (f == pl.nf - 1) ? a.tail_bs : a.B, nch);
-            FA_HIP_TRY(hipMemcpyAsync(dp, h_hdr.data(), (size_t)pl.nf * sizeof(uint4), hipMemcpyHostToDevice, st));
+                ds_->h_hdr[(size_t)f] = frame_header_entry((uint64_t)f, (f == pl.nf - 1) ? a.tail_bs : a.B, nch);
+            FA_HIP_TRY(hipMemcpyAsync(dp, ds_->h_hdr.data(), (size_t)pl.nf * sizeof(uint4), hipMemcpyHostToDevice, st));
             FA_HIP_TRY(hipStreamSynchronize(st));  // h_hdr is reused by the next call
-            c_nf = pl.nf; c_B = a.B; c_tail = a.tail_bs; c_nch = nch; c_dev = dev; c_dp = dp; c_epoch = g_scratch_epoch;
+            ds_->c_nf = pl.nf; ds_->c_B = a.B; ds_->c_tail = a.tail_bs; ds_->c_nch = nch; ds_->c_dp = dp; ds_->c_epoch = ds_->scratch_epoch;
         }
         a.hdr = reinterpret_cast<const uint4*>(dp);
     }
 #ifdef FA_STAMPS
     {
         void* sp = nullptr;
-        static bool zeroed = false;
         if (get_scratch(6, 256, &sp) == 0) {
-            if (!zeroed) { (void)hipMemset(sp, 0, 256); zeroed = true; }
+            if (!ds_->stamps_zeroed) { (void)hipMemset(sp, 0, 256); ds_->stamps_zeroed = true; }
             a.stamps = reinterpret_cast<unsigned long long*>(sp);
         }
     }
@@ -555,6 +585,7 @@ static int encode_device_finish(int nch, int64_t n_stream, int64_t stream_size, 
                           reinterpret_cast<const uint32_t*>(ws + pl.off_fbytes), d_foff, d_starts, pl.nf, pl.F, crc, d_bytes,
                           pl.slot_stride);
     prof_end(1, st);
+    prof_end(3, st);
     FA_HIP_TRY(hipGetLastError());
     return FA_ERROR_NONE;
 }
@@ -646,8 +677,10 @@ int fa_float32_to_int32_device(const float* d_input, int64_t n_stream, int64_t s
     if (rc) return rc;
     int* d_flags = reinterpret_cast<int*>(p);
     FA_HIP_TRY(hipMemsetAsync(d_flags, 0, 4, st));
+    prof_begin(5, st);
     hipLaunchKernelGGL(float32_to_int32_kernel, dim3((unsigned)n_stream), dim3(1024), 0, st, d_input, stream_size, d_quanta,
                        d_output, d_offsets, d_gains, d_flags);
+    prof_end(5, st);
     int h = 0;
     FA_HIP_TRY(hipMemcpyAsync(&h, d_flags, 4, hipMemcpyDeviceToHost, st));
     FA_HIP_TRY(hipStreamSynchronize(st));
@@ -815,11 +848,14 @@ static int decode_host(const unsigned char* bytes, const int64_t* starts, const 
     for (int64_t s0 = 0; s0 < n_stream && !err; s0 += chunk) {
         const int64_t ns = (n_stream - s0 < chunk) ? (n_stream - s0) : chunk;
         int64_t lo = INT64_MAX, hi = 0;
+        bool bad_index = false;
         for (int64_t i = 0; i < ns; ++i) {
+            // the C signature carries no blob length: negative or overflowing entries are all that can be refused here
+            if (starts[s0 + i] < 0 || nbytes[s0 + i] < 0 || starts[s0 + i] > INT64_MAX - nbytes[s0 + i]) { bad_index = true; break; }
             if (starts[s0 + i] < lo) lo = starts[s0 + i];
             if (starts[s0 + i] + nbytes[s0 + i] > hi) hi = starts[s0 + i] + nbytes[s0 + i];
         }
-        if (hi <= lo) { err = FA_ERROR_DECODE_INIT; break; }
+        if (bad_index || hi <= lo) { err = FA_ERROR_DECODE_INIT; break; }
         st_rel.resize((size_t)ns);
         for (int64_t i = 0; i < ns; ++i) st_rel[(size_t)i] = starts[s0 + i] - lo;
         void *d_blob = nullptr, *d_aux = nullptr, *d_out = nullptr;
@@ -892,14 +928,11 @@ int float32_to_int32(float const* input, int64_t n_stream, int64_t stream_size, 
 
 void int32_to_float32(int32_t const* input, int64_t n_stream, int64_t stream_size, float const* offsets,
                       float const* gains, float* output) {
-    FA_API_LOCK;
+    FA_API_LOCK_OR(fatal_device("int32_to_float32", "hipGetDevice"));
     if (n_stream <= 0 || stream_size <= 0) return;
-    if (fa_device_count() <= 0) {
-        std::fprintf(stderr, "flacarray_hip: int32_to_float32 called without a HIP device\n");
-        std::abort();  // the reference signature has no error channel; never fall back silently
-    }
+    if (fa_device_count() <= 0) fatal_device("int32_to_float32", "hipGetDeviceCount (no HIP device)");
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) std::abort();
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) fatal_device("int32_to_float32", "hipMemGetInfo");
     int64_t chunk = (int64_t)((free_b / 10 * 8) / ((size_t)stream_size * 8 + 64));
     if (chunk < 1) chunk = 1;
     if (chunk > n_stream) chunk = n_stream;
@@ -907,19 +940,18 @@ void int32_to_float32(int32_t const* input, int64_t n_stream, int64_t stream_siz
         const int64_t ns = (n_stream - s0 < chunk) ? (n_stream - s0) : chunk;
         const size_t nb = (size_t)ns * (size_t)stream_size * 4;
         void *d_in = nullptr, *d_out = nullptr, *d_aux = nullptr;
-        if (get_scratch(0, nb, &d_in) || get_scratch(5, nb, &d_out) || get_scratch(3, (size_t)ns * 8 + 512, &d_aux)) std::abort();
+        const char* fn = "int32_to_float32";
+        if (get_scratch(0, nb, &d_in) || get_scratch(5, nb, &d_out) || get_scratch(3, (size_t)ns * 8 + 512, &d_aux))
+            fatal_device(fn, "hipMalloc of the staging buffers");
         float* d_off = reinterpret_cast<float*>(d_aux);
         float* d_gain = d_off + ns;
-        bool ok = hipMemcpy(d_in, input + s0 * stream_size, nb, hipMemcpyHostToDevice) == hipSuccess;
-        ok = ok && hipMemcpy(d_off, offsets + s0, (size_t)ns * 4, hipMemcpyHostToDevice) == hipSuccess;
-        ok = ok && hipMemcpy(d_gain, gains + s0, (size_t)ns * 4, hipMemcpyHostToDevice) == hipSuccess;
-        ok = ok && fa_int32_to_float32_device(reinterpret_cast<const int32_t*>(d_in), ns, stream_size, d_off, d_gain,
-                                              reinterpret_cast<float*>(d_out), nullptr) == FA_ERROR_NONE;
-        ok = ok && hipMemcpy(output + s0 * stream_size, d_out, nb, hipMemcpyDeviceToHost) == hipSuccess;
-        if (!ok) {
-            std::fprintf(stderr, "flacarray_hip: int32_to_float32 device failure\n");
-            std::abort();
-        }
+        if (hipMemcpy(d_in, input + s0 * stream_size, nb, hipMemcpyHostToDevice) != hipSuccess) fatal_device(fn, "hipMemcpy(input, H2D)");
+        if (hipMemcpy(d_off, offsets + s0, (size_t)ns * 4, hipMemcpyHostToDevice) != hipSuccess) fatal_device(fn, "hipMemcpy(offsets, H2D)");
+        if (hipMemcpy(d_gain, gains + s0, (size_t)ns * 4, hipMemcpyHostToDevice) != hipSuccess) fatal_device(fn, "hipMemcpy(gains, H2D)");
+        if (fa_int32_to_float32_device(reinterpret_cast<const int32_t*>(d_in), ns, stream_size, d_off, d_gain,
+                                       reinterpret_cast<float*>(d_out), nullptr) != FA_ERROR_NONE)
+            fatal_device(fn, "int32_to_float32_kernel launch");
+        if (hipMemcpy(output + s0 * stream_size, d_out, nb, hipMemcpyDeviceToHost) != hipSuccess) fatal_device(fn, "hipMemcpy(output, D2H)");
     }
 }
 
@@ -958,14 +990,11 @@ int float64_to_int64(double const* input, int64_t n_stream, int64_t stream_size,
 
 void int64_to_float64(int64_t const* input, int64_t n_stream, int64_t stream_size, double const* offsets,
                       double const* gains, double* output) {
-    FA_API_LOCK;
+    FA_API_LOCK_OR(fatal_device("int64_to_float64", "hipGetDevice"));
     if (n_stream <= 0 || stream_size <= 0) return;
-    if (fa_device_count() <= 0) {
-        std::fprintf(stderr, "flacarray_hip: int64_to_float64 called without a HIP device\n");
-        std::abort();  // the reference signature has no error channel; never fall back silently
-    }
+    if (fa_device_count() <= 0) fatal_device("int64_to_float64", "hipGetDeviceCount (no HIP device)");
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) std::abort();
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) fatal_device("int64_to_float64", "hipMemGetInfo");
     int64_t chunk = (int64_t)((free_b / 10 * 8) / ((size_t)stream_size * 16 + 64));
     if (chunk < 1) chunk = 1;
     if (chunk > n_stream) chunk = n_stream;
@@ -973,20 +1002,19 @@ void int64_to_float64(int64_t const* input, int64_t n_stream, int64_t stream_siz
         const int64_t ns = (n_stream - s0 < chunk) ? (n_stream - s0) : chunk;
         const size_t nb = (size_t)ns * (size_t)stream_size * 8;
         void *d_in = nullptr, *d_out = nullptr, *d_aux = nullptr;
-        if (get_scratch(0, nb, &d_in) || get_scratch(5, nb, &d_out) || get_scratch(3, (size_t)ns * 16 + 512, &d_aux)) std::abort();
+        const char* fn = "int64_to_float64";
+        if (get_scratch(0, nb, &d_in) || get_scratch(5, nb, &d_out) || get_scratch(3, (size_t)ns * 16 + 512, &d_aux))
+            fatal_device(fn, "hipMalloc of the staging buffers");
         double* d_off = reinterpret_cast<double*>(d_aux);
         double* d_gain = d_off + ns;
-        bool ok = hipMemcpy(d_in, input + s0 * stream_size, nb, hipMemcpyHostToDevice) == hipSuccess;
-        ok = ok && hipMemcpy(d_off, offsets + s0, (size_t)ns * 8, hipMemcpyHostToDevice) == hipSuccess;
-        ok = ok && hipMemcpy(d_gain, gains + s0, (size_t)ns * 8, hipMemcpyHostToDevice) == hipSuccess;
-        ok = ok && fa_int64_to_float64_device(reinterpret_cast<const int64_t*>(d_in), ns, stream_size, d_off, d_gain,
-                                              reinterpret_cast<double*>(d_out), nullptr) == FA_ERROR_NONE;
-        ok = ok && hipStreamSynchronize(nullptr) == hipSuccess;
-        ok = ok && hipMemcpy(output + s0 * stream_size, d_out, nb, hipMemcpyDeviceToHost) == hipSuccess;
-        if (!ok) {
-            std::fprintf(stderr, "flacarray_hip: int64_to_float64 device failure\n");
-            std::abort();
-        }
+        if (hipMemcpy(d_in, input + s0 * stream_size, nb, hipMemcpyHostToDevice) != hipSuccess) fatal_device(fn, "hipMemcpy(input, H2D)");
+        if (hipMemcpy(d_off, offsets + s0, (size_t)ns * 8, hipMemcpyHostToDevice) != hipSuccess) fatal_device(fn, "hipMemcpy(offsets, H2D)");
+        if (hipMemcpy(d_gain, gains + s0, (size_t)ns * 8, hipMemcpyHostToDevice) != hipSuccess) fatal_device(fn, "hipMemcpy(gains, H2D)");
+        if (fa_int64_to_float64_device(reinterpret_cast<const int64_t*>(d_in), ns, stream_size, d_off, d_gain,
+                                       reinterpret_cast<double*>(d_out), nullptr) != FA_ERROR_NONE)
+            fatal_device(fn, "int64_to_float64_kernel launch");
+        if (hipStreamSynchronize(nullptr) != hipSuccess) fatal_device(fn, "hipStreamSynchronize");
+        if (hipMemcpy(output + s0 * stream_size, d_out, nb, hipMemcpyDeviceToHost) != hipSuccess) fatal_device(fn, "hipMemcpy(output, D2H)");
     }
 }
 

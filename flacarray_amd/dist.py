@@ -30,6 +30,20 @@ def shard_counts(n_stream, world_size):
     return [shard_range(n_stream, world_size, r)[1] - shard_range(n_stream, world_size, r)[0] for r in range(world_size)]
 
 
+def _settle(t):
+    """Rule for every exchange in this module: a payload is handed to the backend only after the stream
+    that produced it has drained, and collectives are issued against torch's CURRENT stream -- the stream
+    the encode / decode kernels were launched on (libflacarray.py:_stream_ptr) -- never a side stream.
+    The C entry points already end with a hipStreamSynchronize of that stream (the byte total goes to
+    the host), so this costs nothing; it makes the ordering explicit instead of implied.  See DESIGN.md
+    section 6 for what this rule has to do with the two-ranks-on-one-GPU rehearsal hang of round 1."""
+    if t.is_cuda:
+        import torch
+
+        torch.cuda.current_stream(t.device).synchronize()
+    return t
+
+
 def gather_stream_nbytes(local_nbytes, n_stream_global, group=None):
     """All-gather the per-stream byte counts; returns (global nbytes int64[n_stream_global],
     global starts int64[n_stream_global], per-rank byte totals list)."""
@@ -40,6 +54,7 @@ def gather_stream_nbytes(local_nbytes, n_stream_global, group=None):
     counts = shard_counts(n_stream_global, world)
     maxc = max(counts)
     dev = local_nbytes.device
+    _settle(local_nbytes)
     # RCCL moves device tensors; gloo gets the (small) table through the host, also when the data
     # lives on a GPU (its device-tensor all-gather does not complete when ranks share a device)
     cdev = dev if dist.get_backend(group) == "nccl" else torch.device("cpu")
@@ -68,6 +83,7 @@ def all_gather_blobs(local_blob, rank_bytes, group=None):
     rank = dist.get_rank(group)
     offs = np.concatenate([[0], np.cumsum(rank_bytes)]).astype(np.int64)
     dev = local_blob.device
+    _settle(local_blob)
     if world > 1 and dist.get_backend(group) != "nccl" and dev.type != "cpu":
         # gloo: point-to-point transfers of host tensors
         return all_gather_blobs(local_blob.cpu(), rank_bytes, group).to(dev)
@@ -97,3 +113,68 @@ def assemble_global(local_blob, local_nbytes, n_stream_global, group=None):
     g_nbytes, g_starts, rank_bytes = gather_stream_nbytes(local_nbytes, n_stream_global, group)
     blob = all_gather_blobs(local_blob, rank_bytes, group)
     return blob, g_starts, g_nbytes
+
+
+def owner_of(streams, n_stream_global, world_size):
+    """Rank that owns each GLOBAL flat stream index under shard_range (vectorised inverse of it)."""
+    streams = np.asarray(streams, dtype=np.int64)
+    base, rem = divmod(int(n_stream_global), int(world_size))
+    cut = rem * (base + 1)  # the first `rem` ranks hold base+1 streams
+    if base == 0:
+        return streams.copy()  # fewer streams than ranks: stream i lives on rank i
+    return np.where(streams < cut, streams // (base + 1), rem + (streams - cut) // base)
+
+
+def route_slices(local_store, streams, first, count, n_stream_global, group=None, gather=False):
+    """Owner-routed scattered decode over a sharded store (cfg 5).
+
+    Every rank holds `local_store`, the FlacArray of ITS contiguous range of streams (shard_range; the
+    reference distributes the leading axis the same way, mpi.py:84-90), ideally resident in HBM
+    (FlacArray.to_device).  All ranks pass the same request table: `streams` are GLOBAL flat stream
+    indices, `first` / `count` sample ranges -- the reference would serve it with one decode call per
+    request (array.py:409-449).  Each request is decoded by the rank that owns its stream, in one
+    batched launch per rank; no compressed byte moves between GPUs.
+
+    gather=False: returns (idx, outs) -- the positions of this rank's requests in the table and their
+    decoded arrays ("outputs returned to host per GPU").
+    gather=True: additionally all-gathers the decoded samples (all-gather-v, same transport as
+    all_gather_blobs) and returns the list of all outputs in request order on every rank.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    streams = np.asarray(streams, dtype=np.int64)
+    first = np.asarray(first, dtype=np.int64)
+    count = np.asarray(count, dtype=np.int64)
+    if streams.size and (streams.min() < 0 or streams.max() >= n_stream_global):
+        raise RuntimeError("route_slices: stream index outside the global array")
+    lo, hi = shard_range(n_stream_global, world, rank)
+    if local_store.nstreams != hi - lo:
+        raise RuntimeError(f"route_slices: rank {rank} holds {local_store.nstreams} streams, its shard has {hi - lo}")
+    owner = owner_of(streams, n_stream_global, world)
+    idx = np.flatnonzero(owner == rank)
+    if not gather:
+        outs = local_store.read_slices(streams[idx] - lo, first[idx], count[idx]) if idx.size else []
+        return idx, outs
+    # decoded samples of every rank, concatenated in rank order, then cut back into request order
+    if idx.size:
+        flat, _ = local_store.read_slices(streams[idx] - lo, first[idx], count[idx], as_tensor=True)
+    else:
+        res = getattr(local_store, "_resident", None)
+        dev = res["device"] if res else torch.device("cpu")
+        flat = torch.zeros(0, dtype=getattr(torch, local_store.typestr), device=dev)
+    esz = flat.element_size()
+    per_rank = [int(count[owner == r].sum()) * esz for r in range(world)]
+    blob = flat.view(torch.uint8) if world == 1 else all_gather_blobs(flat.view(torch.uint8), per_rank, group)
+    allv = blob.view(flat.dtype).cpu().numpy()
+    outs = [None] * streams.size
+    base = 0
+    for r in range(world):
+        ridx = np.flatnonzero(owner == r)
+        offs = base + np.concatenate([[0], np.cumsum(count[ridx])[:-1]]) if ridx.size else []
+        for i, o in zip(ridx, offs):
+            outs[i] = allv[int(o) : int(o) + int(count[i])]
+        base += int(count[ridx].sum())
+    return outs

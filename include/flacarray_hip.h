@@ -168,6 +168,10 @@ int fa_int64_to_float64_device(const int64_t* d_input, int64_t n_stream, int64_t
  * (-1 for a kernel that has not run). */
 void fa_profile_enable(int on);
 int fa_profile_last(float* ms3);
+/* The same with more pairs: ms[0..n) = {encode_frames_kernel, compact_frames_kernel, decode_frames_kernel<8>,
+ * whole encode sequence (first launch of _begin .. last launch of _finish, host gaps included),
+ * whole decode sequence (K6 + K7), float32_to_int32_kernel}; n <= 6. */
+int fa_profile_read(float* ms, int n);
 
 /* free the library's cached device scratch (decode tables, staging buffers) */
 void fa_release_scratch(void);

@@ -11,6 +11,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the checker is compiled here, before any test can have initialised the GPU (oracle.lib() never builds)
+    from oracle import oracle as O
+
+    O.build()
 
 
 def sinusoid_noise_i32(n_ch, n_samp, seed=123456789, amp=2**16):

@@ -237,8 +237,9 @@ def test_read_slices_batched(fa):
 
 
 def test_full_size_properties(fa):
-    """BASELINE.json's full-size shape (per-stream 2^20 samples; 1024 channels here to keep the GPU
-    suite short) through size-independent properties: decode(encode(x)) == x, nbytes/starts are a
+    """BASELINE.json's configuration 2 at its stated size -- 4096 channels x 2^20 int32: 16 GiB of input,
+    17.4 GB of frame slots and a 9.8 GB blob, so slot and blob byte offsets pass 2^32 -- through
+    size-independent properties: decode(encode(x)) == x, nbytes/starts are a
     consistent exclusive scan, every stream is self-contained (decoding a shuffled subset through
     its own starts/nbytes gives the same rows), slices equal the corresponding part of the full
     decode, and a 64-bit checksum of the decoded matrix equals the input's."""
@@ -247,9 +248,10 @@ def test_full_size_properties(fa):
     import bench
 
     dev = torch.device("cuda", 0)
-    n_ch, n = 1024, 1 << 20
+    n_ch, n = 4096, 1 << 20
     x = bench.make_data(torch, n_ch, n, 2024, dev)
     comp, st, nb = fa.encode_flac_device(x, level=5)
+    assert comp.numel() > 2**32 and int(st[-1]) > 2**32  # the offsets this test exists for
     assert int(st[0]) == 0 and torch.equal(torch.cumsum(nb, 0) - nb, st) and int(st[-1] + nb[-1]) == comp.numel()
     y = fa.decode_flac_device(comp, st, nb, n)
     assert torch.equal(y, x)
@@ -259,6 +261,130 @@ def test_full_size_properties(fa):
     assert torch.equal(ys, x[sel, 500000 : 500000 + 70001])
     ratio = comp.numel() / (4.0 * x.numel())
     assert 0.5 < ratio < 0.65  # c/4 of the sinusoid+noise workload (SURVEY.md 8d expects 0.55-0.6)
+    # every stream is a complete FLAC stream of its own: marker, and the oracle decodes a few of them
+    # (first, last, one past the 2^32-byte mark) from nothing but their own bytes
+    from oracle import oracle as O
+
+    past = int(torch.searchsorted(st, torch.tensor(2**32, device=dev)))
+    for s_i in (0, past, n_ch - 1):
+        b0, b1 = int(st[s_i]), int(st[s_i] + nb[s_i])
+        one = comp[b0:b1].cpu().numpy()
+        assert bytes(one[:4]) == b"fLaC"
+        yo = O.decode_i32(one, np.zeros(1, np.int64), np.array([b1 - b0], np.int64), n)
+        assert np.array_equal(yo.reshape(-1), x[s_i].cpu().numpy())
+    del y, ys, comp
+    torch.cuda.empty_cache()
+
+
+def _make_float_field(torch, n_ch, n_samp, seed, dev):
+    """S3 of SURVEY.md 8(d): the sinusoid+noise field before rint, float32, amplitude 1, generated on the device."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    out = torch.empty((n_ch, n_samp), dtype=torch.float32, device=dev)
+    t = torch.arange(n_samp, device=dev, dtype=torch.float32)
+    f = 5.0 / n_samp
+    wave = 2.0 * torch.sin(2 * np.pi * 3 * f * t) + 6.0 * torch.sin(2 * np.pi * f * t)
+    for c0 in range(0, n_ch, 64):
+        c1 = min(n_ch, c0 + 64)
+        dc = 5.0 * (torch.rand((c1 - c0, 1), generator=g, device=dev) - 0.5)
+        sc = torch.rand((c1 - c0, 1), generator=g, device=dev)
+        out[c0:c1] = dc + sc * wave + torch.randn((c1 - c0, n_samp), generator=g, device=dev)
+    return out
+
+
+def test_cfg3_full_length_float(fa, oracle):
+    """BASELINE.json's configuration 3 at full stream length: 1024 channels x 2^20 float32 with per-channel
+    quanta 2^-16 (1 + c mod 4): quantise -> encode -> decode with the fused restore.
+    Properties: |x^ - x| <= quanta/2 (+ float32 rounding of the subtract / add, as the reference's own
+    bound, tests/array.py:251-260); gains == 1/quanta; offsets are whole multiples of the quanta; and the
+    first / last channel's integers, offset and gain are bit-equal to the oracle's (utils.c:160-243)."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    n_ch, n = 1024, 1 << 20
+    x = _make_float_field(torch, n_ch, n, 31337, dev)
+    q = (2.0**-16 * (1 + torch.arange(n_ch, device=dev) % 4)).to(torch.float32)
+    ints, off, gain = fa.float32_to_int32_device(x, q)
+    comp, st, nb = fa.encode_flac_device(ints, level=5)
+    y = fa.decode_flac_device(comp, st, nb, n, offsets=off, gains=gain)
+    assert y.dtype == torch.float32 and y.shape == x.shape
+    eps = float(np.finfo(np.float32).eps)
+    tol = 0.5 * q[:, None] + 4 * eps * (x.abs() + off.abs()[:, None])
+    assert bool(((y - x).abs() <= tol).all())
+    assert torch.equal(gain, (1.0 / q.double()).float())
+    ratio = off.double() / q.double()
+    assert bool((ratio == ratio.round()).all())
+    # the decoded integers are the quantised ones (the int path under the float path is lossless)
+    assert torch.equal(fa.decode_flac_device(comp, st, nb, n), ints)
+    for c in (0, n_ch - 1):
+        io, offo, go = oracle.float32_to_int32(x[c : c + 1].cpu().numpy(), q[c : c + 1].cpu().numpy())
+        assert np.array_equal(ints[c].cpu().numpy(), io.reshape(-1))
+        assert offo.view(np.uint32)[0] == off[c : c + 1].cpu().numpy().view(np.uint32)[0]
+        assert go.view(np.uint32)[0] == gain[c : c + 1].cpu().numpy().view(np.uint32)[0]
+
+
+def test_corrupt_index_rejected(fa, oracle):
+    """A damaged index (stream_starts / stream_nbytes pointing outside the blob, negative entries) must come
+    back as ERROR_DECODE_INIT, never as an out-of-range device read."""
+    import torch
+
+    x = sinusoid_noise_i32(3, 9000, seed=8)
+    blob, st, nb = oracle.encode_i32(x, 5)
+    d_blob = torch.from_numpy(blob).cuda()
+    for bad_st, bad_nb in (
+        (st + np.array([0, 10**12, 0]), nb),           # start far past the end
+        (st, nb + np.array([0, 0, 10**9])),            # length runs off the end
+        (st * np.array([1, -1, 1]) - np.array([0, 1, 0]), nb),  # negative start
+        (st, nb * np.array([1, -1, 1])),               # negative length
+        (np.full(3, blob.size, np.int64), nb),         # start == blob size
+    ):
+        with pytest.raises(RuntimeError, match="Decoding failed"):
+            fa.decode_flac_device(d_blob, torch.from_numpy(bad_st.astype(np.int64)).cuda(), torch.from_numpy(bad_nb.astype(np.int64)).cuda(), 9000)
+    with pytest.raises(RuntimeError, match="Decoding failed"):
+        fa.decode_flac(blob, st * np.array([1, -1, 1]) - np.array([0, 1, 0]), nb, 9000)  # host ABI: negative start
+    # the intact index still decodes
+    assert np.array_equal(fa.decode_flac_device(d_blob, torch.from_numpy(st).cuda(), torch.from_numpy(nb).cuda(), 9000).cpu().numpy(), x)
+
+
+def test_resident_flacarray(fa):
+    """A FlacArray made resident with to_device() answers every read like the host-backed one (and like numpy),
+    int32 and quantised float32, without re-uploading the store."""
+    import torch
+
+    x = sinusoid_noise_i32(24, 20000, seed=31).reshape(4, 6, 20000)
+    xf = sinusoid_noise_f32(24, 20000, seed=32).reshape(4, 6, 20000)
+    for arr, kw in ((x, {}), (xf, {"quanta": 1e-4})):
+        host = fa.FlacArray.from_array(arr, **kw)
+        ref = host.to_array()
+        res = fa.FlacArray(host).to_device()
+        assert res.is_resident and not host.is_resident
+        keys = [
+            (slice(None),), (1,), (1, 2), (1, 2, slice(5, 9000)), (slice(1, 3), slice(None), slice(100, 101)),
+            (slice(None), 3, 19999), (slice(0, 4, 2), slice(5, 0, -2)), (3, 5, slice(4096, 8192)),
+        ]
+        for key in keys:
+            a, b = host[key], res[key]
+            assert a.shape == b.shape == ref[key].shape, key
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), key
+        assert np.array_equal(res.to_array().view(np.uint32), ref.view(np.uint32))
+        assert np.array_equal(res.to_array(stream_slice=slice(7, 4500)).view(np.uint32), ref[..., 7:4500].view(np.uint32))
+        keep = np.zeros((4, 6), bool)
+        keep[0, 1] = keep[3, 5] = keep[2, 2] = True
+        a, ia = host.to_array(keep=keep, keep_indices=True)
+        b, ib = res.to_array(keep=keep, keep_indices=True)
+        assert ia == ib and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        rng = np.random.default_rng(5)
+        streams = rng.integers(0, 24, 200)
+        cnt = rng.integers(1, 9000, 200)
+        first = np.array([rng.integers(0, 20000 - c + 1) for c in cnt])
+        flat = ref.reshape(24, -1)
+        for o, s_i, f0, c in zip(res.read_slices(streams, first, cnt), streams, first, cnt):
+            assert np.array_equal(o.view(np.uint32), flat[s_i, f0 : f0 + c].view(np.uint32))
+    # built on the device, never leaves it: from_device_array
+    d = torch.from_numpy(x.reshape(24, -1)).cuda()
+    r2 = fa.FlacArray.from_device_array(d)
+    assert r2.is_resident and r2 == fa.FlacArray.from_array(x.reshape(24, -1))
+    assert np.array_equal(r2[5, 100:300], x.reshape(24, -1)[5, 100:300])
 
 
 @pytest.mark.parametrize("level,n", [(5, 100000), (0, 50001), (8, 4096 * 3)])

@@ -23,6 +23,32 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in _lib.lib().fa_version()
 
 
+def test_reference_named_header_compiles_without_libflac(tmp_path):
+    """include/flacarray.h is what `cdef extern from "flacarray.h"` (libflacarray.pyx:18) finds when the binding
+    is built against this library: the ten prototypes the binding declares (libflacarray.pyx:19-110) and the
+    reference's unprefixed error names, with no <FLAC/...> include."""
+    import subprocess
+
+    text = open(os.path.join(ROOT, "include", "flacarray.h")).read()
+    assert "#include <FLAC" not in text and "#include" in text
+    src = tmp_path / "use.c"
+    src.write_text(
+        '#include "flacarray.h"\n'
+        "int use(void) {\n"
+        "  void* f[] = {(void*)encode_i32, (void*)encode_i32_threaded, (void*)encode_i64, (void*)encode_i64_threaded,\n"
+        "               (void*)decode_i32, (void*)decode_i64, (void*)float32_to_int32, (void*)float64_to_int64,\n"
+        "               (void*)int32_to_float32, (void*)int64_to_float64};\n"
+        "  return (int)sizeof f + ERROR_NONE + ERROR_ALLOC + ERROR_INVALID_LEVEL + ERROR_ZERO_NSTREAM + ERROR_ZERO_STREAMSIZE +\n"
+        "         ERROR_ENCODE_INIT + ERROR_ENCODE_PROCESS + ERROR_DECODE_INIT + ERROR_DECODE_PROCESS + ERROR_DECODE_STREAMSIZE +\n"
+        "         ERROR_DECODE_SAMPLE_RANGE + ERROR_DECODE_SEEK + ERROR_CONVERT_TYPE + ERROR_ENCODE_FINISH + ERROR_DECODE_FINISH;\n"
+        "}\n"
+    )
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-Wno-pedantic", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])
+    # same bit values as the reference's table (flacarray.h:20-40)
+    vals = dict(re.findall(r"#define (FA_ERROR_\w+) \(1 << (\d+)\)", open(os.path.join(ROOT, "include", "flacarray_hip.h")).read()))
+    assert vals["FA_ERROR_DECODE_INIT"] == "13" and vals["FA_ERROR_DECODE_SAMPLE_RANGE"] == "17" and vals["FA_ERROR_CONVERT_TYPE"] == "19"
+
+
 def test_no_silent_cpu_fallback():
     if _lib.lib().fa_device_count() > 0:
         pytest.skip("a GPU is present")
