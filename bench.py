@@ -5,7 +5,7 @@
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 One step = one pass of the hot path over one batch: encode the HBM-resident int32 matrix
-(K3 analyse+pack, K4 scan, K5 headers+compaction+CRC) into the reference's
+(K3F: analyse, size, place and write every frame in one kernel, then the stream headers) into the reference's
 (compressed, starts, nbytes) triple, then decode that triple back to int32 (K6 index, K7 decode).
 Weak scaling: every rank owns its own 4096 channels (contiguous leading-axis shard, the
 reference's mpi.py:84-90 distribution); no data-path collective -- only the per-stream byte
@@ -48,21 +48,19 @@ def make_data(torch, n_ch, n_samp, seed, device):
 
 
 def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the most recent committed PMC measurement
+    """HBM bytes per launch of `kernel` from the most recent committed PMC measurement that has this kernel
     (profiles/r*_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
     command, corrected as MI355X_MICROARCH.md prescribes); None if there is none."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-    if not files:
-        return None
-    try:
-        data = json.load(open(files[-1]))
-        for name, rec in data["kernels"].items():
-            if kernel in name:
-                return round(rec["hbm_bytes"] / 1e9, 3)
-    except Exception:
-        return None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            data = json.load(open(path))
+            for name, rec in data["kernels"].items():
+                if kernel in name:
+                    return round(rec["hbm_bytes"] / 1e9, 3)
+        except Exception:
+            continue
     return None
 
 
@@ -127,8 +125,9 @@ def profile_read(L, n=6):
 
 
 def bench_cfg3(torch, fa, L, n_ch, n_samp, level, dev, steps=3):
-    """Configuration 3 on one GPU: float32 in -> quantise (per-channel quanta) -> encode -> decode with the
-    fused restore -> float32 out.  Reported beside the headline, never as `value`."""
+    """Configuration 3 on one GPU: float32 in -> range pre-pass -> encode with the quantisation (per-channel quanta)
+    fused into the staging load -> decode with the fused restore -> float32 out.  Reported beside the headline, never
+    as `value`."""
     from flacarray_amd.libflacarray import EncodeWorkspace
 
     xf = make_float_data(torch, n_ch, n_samp, 31337, dev)
@@ -136,8 +135,7 @@ def bench_cfg3(torch, fa, L, n_ch, n_samp, level, dev, steps=3):
     ws = EncodeWorkspace()
 
     def step():
-        ints, off, gain = fa.float32_to_int32_device(xf, q)
-        comp, st, nb = fa.encode_flac_device(ints, level=level, workspace=ws)
+        comp, st, nb, off, gain = fa.encode_flac_device_f32(xf, q, level=level, workspace=ws)
         return fa.decode_flac_device(comp, st, nb, n_samp, offsets=off, gains=gain), comp
 
     y, comp = step()
@@ -157,7 +155,7 @@ def bench_cfg3(torch, fa, L, n_ch, n_samp, level, dev, steps=3):
         "workload": f"{n_ch}ch x {n_samp} float32, per-channel quanta 2^-16 (1 + c mod 4), level {level}: quantise, encode, decode + restore",
         "ms_per_step": round(dt * 1e3, 3),
         "Msamples_per_s": round(n_ch * n_samp / dt / 1e6, 1),
-        "float32_to_int32_kernel_ms": round(float(np.mean(k1)), 3),
+        "range_prepass_ms": round(float(np.mean(k1)), 3),  # K1a + K1b (min / max per stream); the quantisation itself runs inside the encoder
         "compressed_bytes_per_sample": round(comp.numel() / xf.numel(), 4),
         "max_abs_err_in_half_quanta": round(err, 4),
     }
@@ -315,12 +313,15 @@ def main():
         n_local = n_ch * n_samp
         alg_gb = (4 + c_bytes) * n_local / 1e9  # algorithmic bytes of one direction: 4 + c per sample
         gbs = lambda ms: round(alg_gb / (ms * 1e-3), 1) if ms > 0 else None  # noqa: E731
+        single_pass = cmpm <= 0  # the single-pass encoder ran: there is no compaction kernel
+        enc_name = "encode_fused_kernel" if single_pass else "encode_frames_kernel"
         kernels = {
-            "encode_frames_kernel": {"ms": round(enc, 3), "algorithmic_GBs": gbs(enc)},
-            "compact_frames_kernel": {"ms": round(cmpm, 3), "algorithmic_GBs": round(2 * c_bytes * n_local / (cmpm * 1e-3) / 1e9, 1) if cmpm > 0 else None},
+            enc_name: {"ms": round(enc, 3), "algorithmic_GBs": gbs(enc)},
             "decode_frames_kernel": {"ms": round(dec, 3), "algorithmic_GBs": gbs(dec)},
         }
-        dom = max(("encode_frames_kernel", "decode_frames_kernel"), key=lambda k: kernels[k]["ms"])
+        if not single_pass:
+            kernels["compact_frames_kernel"] = {"ms": round(cmpm, 3), "algorithmic_GBs": round(2 * c_bytes * n_local / (cmpm * 1e-3) / 1e9, 1)}
+        dom = max((enc_name, "decode_frames_kernel"), key=lambda k: kernels[k]["ms"])
         achieved = kernels[dom]["algorithmic_GBs"]
         out = {
             "metric": "Msamples/s encode+decode, 4096ch x 1Msamp int32",

@@ -15,6 +15,7 @@ from .libflacarray import (
     decode_slices_device,
     encode_flac,
     encode_flac_device,
+    encode_flac_device_f32,
     float32_to_int32_device,
 )
 from .utils import float_to_int, int_to_float, keep_select
@@ -34,6 +35,7 @@ __all__ = [
     "encode_flac",
     "decode_flac",
     "encode_flac_device",
+    "encode_flac_device_f32",
     "decode_flac_device",
     "decode_slices_device",
     "float32_to_int32_device",

@@ -24,6 +24,11 @@ SYMBOLS = [
     "fa_encode_workspace_bytes",
     "fa_encode_i32_device_begin",
     "fa_encode_i32_device_finish",
+    "fa_encode_single_pass_supported",
+    "fa_encode_capacity_bytes",
+    "fa_encode_single_pass_workspace_bytes",
+    "fa_encode_i32_device",
+    "fa_encode_f32_device",
     "fa_decode_i32_device",
     "fa_decode_slices_i32_device",
     "fa_decode_i64_device",
@@ -87,6 +92,16 @@ def lib():
     L.fa_encode_i32_device_begin.restype = cint
     L.fa_encode_i32_device_finish.argtypes = [i64, i64, u32, vp, vp, vp, vp]
     L.fa_encode_i32_device_finish.restype = cint
+    L.fa_encode_single_pass_supported.argtypes = [i64, i64, u32]
+    L.fa_encode_single_pass_supported.restype = cint
+    L.fa_encode_capacity_bytes.argtypes = [i64, i64, u32]
+    L.fa_encode_capacity_bytes.restype = i64
+    L.fa_encode_single_pass_workspace_bytes.argtypes = [i64, i64, u32]
+    L.fa_encode_single_pass_workspace_bytes.restype = i64
+    L.fa_encode_i32_device.argtypes = [vp, i64, i64, u32, vp, i64, vp, i64, vp, vp, pi64, vp, vp]
+    L.fa_encode_i32_device.restype = cint
+    L.fa_encode_f32_device.argtypes = [vp, i64, i64, u32, vp, vp, i64, vp, i64, vp, vp, vp, vp, pi64, vp, vp]
+    L.fa_encode_f32_device.restype = cint
     L.fa_decode_i32_device.argtypes = [vp, i64, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, vp]
     L.fa_decode_i32_device.restype = cint
     L.fa_decode_slices_i32_device.argtypes = [vp, i64, vp, vp, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]

@@ -424,20 +424,20 @@ class FlacArray:
         it to host arrays so that every property of the reference API still answers with numpy."""
         import torch
 
-        from .libflacarray import encode_flac_device, float32_to_int32_device
+        from .libflacarray import encode_flac_device, encode_flac_device_f32
 
         offsets = gains = None
-        ints = data
         if data.dtype == torch.float32:
             if quanta is None:
                 raise RuntimeError("Compressing floating point data ('float32') requires specifying either quanta or precision.")
             lead = tuple(data.shape[:-1]) if data.dim() > 1 else (1,)
             q = torch.as_tensor(quanta, dtype=torch.float32, device=data.device)
             q = q.expand(lead).contiguous() if q.dim() == 0 else q
-            ints, offsets, gains = float32_to_int32_device(data.contiguous(), q)
-        elif data.dtype not in (torch.int32, torch.int64):
+            comp, st, nb, offsets, gains = encode_flac_device_f32(data.contiguous(), q, level=level, compact=True)
+        elif data.dtype in (torch.int32, torch.int64):
+            comp, st, nb = encode_flac_device(data.contiguous(), level=level, compact=True)
+        else:
             raise ValueError(f"Unsupported data type '{data.dtype}'")
-        comp, st, nb = encode_flac_device(ints.contiguous(), level=level)
         shape = tuple(data.shape)
         out = FlacArray(
             None,

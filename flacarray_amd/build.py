@@ -68,7 +68,9 @@ def build(force=False, verbose=False):
 
 
 def build_variant(name, defines, verbose=False):
-    """Compile a (diagnostic) variant lib/libflacarray_hip_<name>.so with extra -D flags."""
+    """Compile a (diagnostic) variant lib/libflacarray_hip_<name>.so with extra -D flags (single unit, default
+    scheduling strategy unless the flags say otherwise).  -DFA_DEV_MINIMAL instantiates the level 3-5 int32 kernels
+    only: seconds instead of minutes."""
     out = OUT if not name else OUT.replace(".so", f"_{name}.so")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

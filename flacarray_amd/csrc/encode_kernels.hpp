@@ -828,84 +828,90 @@ __global__ __launch_bounds__(64) FA_K3_WAVES_ATTR void encode_frames_kernel(Enco
                 double acc[MLO + 1];
 #pragma unroll
                 for (int j = 0; j <= MLO; ++j) acc[j] = 0.0;
+                // Lane l accumulates its lag products over samples [32 l, 32 l + 32) and then [2048 + 32 l, 2048 + 32 l + 32)
+                // (those below bs): the summation order of the specification, shared with the single-pass kernel
+                // (encode_fused.hpp), whose frame image is split that way.  Only these sums round, so only they fix an order.
                 if (fuse_search) {
                     // every lane is active; one basic block: 64 samples of lag products + the search
-                    const int cbase = kChunkStride * (lane + 1);
-                    const int g0 = kChunk * lane;
-                    float4 wv[16];
-                    float wh[MLO];
-#pragma unroll
-                    for (int t = 0; t < 16; ++t) wv[t] = *reinterpret_cast<const float4*>(win + g0 + 4 * t);
-#pragma unroll
-                    for (int j = 0; j < MLO; ++j) wh[j] = (g0 - 1 - j >= 0) ? win[g0 - 1 - j] : 0.0f;
-                    double hist[MLO];
-#pragma unroll
-                    for (int j = 0; j < MLO; ++j) hist[j] = (double)smp[cbase - kChunkStride + 63 - j] * (double)wh[j];
                     FastRiceSearch fs;
                     fs.start((uint32_t)tl_fix, bs, fo, pmax_fix, lane);
 #pragma unroll
-                    for (int t = 0; t < 16; ++t) {
-                        int4 xv = *reinterpret_cast<const int4*>(&smp[cbase + 4 * t]);
-                        const int xs[4] = {xv.x, xv.y, xv.z, xv.w};
-                        const float ws[4] = {wv[t].x, wv[t].y, wv[t].z, wv[t].w};
+                    for (int piece = 0; piece < 2; ++piece) {
+                        const int g0 = 2048 * piece + 32 * lane;
+                        const int pbase = smp_idx(g0);
+                        float4 wv[8];
+                        float wh[MLO];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const double d = (double)xs[e] * (double)ws[e];
-                            acc[0] = __builtin_fma(d, d, acc[0]);
+                        for (int t = 0; t < 8; ++t) wv[t] = *reinterpret_cast<const float4*>(win + g0 + 4 * t);
 #pragma unroll
-                            for (int j = 0; j < MLO; ++j) acc[j + 1] = __builtin_fma(d, hist[j], acc[j + 1]);
+                        for (int j = 0; j < MLO; ++j) wh[j] = (g0 - 1 - j >= 0) ? win[g0 - 1 - j] : 0.0f;
+                        double hist[MLO];
 #pragma unroll
-                            for (int j = MLO - 1; j > 0; --j) hist[j] = hist[j - 1];
-                            hist[0] = d;
+                        for (int j = 0; j < MLO; ++j) hist[j] = (double)smp[smp_idx(g0 - 1 - j)] * (double)wh[j];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            int4 xv = *reinterpret_cast<const int4*>(&smp[pbase + 4 * t]);
+                            const int xs[4] = {xv.x, xv.y, xv.z, xv.w};
+                            const float ws[4] = {wv[t].x, wv[t].y, wv[t].z, wv[t].w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const double d = (double)xs[e] * (double)ws[e];
+                                acc[0] = __builtin_fma(d, d, acc[0]);
+#pragma unroll
+                                for (int j = 0; j < MLO; ++j) acc[j + 1] = __builtin_fma(d, hist[j], acc[j + 1]);
+#pragma unroll
+                                for (int j = MLO - 1; j > 0; --j) hist[j] = hist[j - 1];
+                                hist[0] = d;
+                            }
+                            // one stage of the search per group of 4 samples (tt is a constant after unrolling)
+                            const int tt = 8 * piece + t;
+                            if (tt == 1) fs.gather();
+                            if (tt == 3) fs.params();
+                            if (tt == 5) fs.totals();
+                            if (tt >= 7 && tt <= 12) fs.order(12 - tt);
                         }
-                        // one stage of the search per group of 4 samples (t is a constant after unrolling)
-                        if (t == 1) fs.gather();
-                        if (t == 3) fs.params();
-                        if (t == 5) fs.totals();
-                        if (t >= 7 && t <= 12) fs.order(12 - t);
                     }
                     po_fix = fs.bpo;
                     k_fix = fs.kb;
                     est_fix = 8 + (uint64_t)wasted + (uint64_t)fo * (uint64_t)bps + (uint64_t)fs.best;
-                } else if (active) {
-                    const int cbase = kChunkStride * (lane + 1);
-                    const int g0 = kChunk * lane;
-                    // the lane's 64 window values (and the MLO before them) are requested up
-                    // front so that one memory round trip covers the whole phase
-                    float4 wv[16];
-                    float wh[MLO];
-                    if (full) {
+                } else {
+#pragma unroll 1
+                    for (int piece = 0; piece < 2; ++piece) {
+                        const int g0 = 2048 * piece + 32 * lane;
+                        if (g0 < bs) {
+                            const int pbase = smp_idx(g0);
+                            float4 wv[8];
+                            float wh[MLO];
 #pragma unroll
-                        for (int t = 0; t < 16; ++t) wv[t] = *reinterpret_cast<const float4*>(win + g0 + 4 * t);
-                    } else {
+                            for (int t = 0; t < 8; ++t) {
+                                const int gb = g0 + 4 * t;
+                                wv[t].x = (gb + 0 < bs) ? win[gb + 0] : 0.0f;
+                                wv[t].y = (gb + 1 < bs) ? win[gb + 1] : 0.0f;
+                                wv[t].z = (gb + 2 < bs) ? win[gb + 2] : 0.0f;
+                                wv[t].w = (gb + 3 < bs) ? win[gb + 3] : 0.0f;
+                            }
 #pragma unroll
-                        for (int t = 0; t < 16; ++t) {
-                            const int gb = g0 + 4 * t;
-                            wv[t].x = (gb + 0 < bs) ? win[gb + 0] : 0.0f;
-                            wv[t].y = (gb + 1 < bs) ? win[gb + 1] : 0.0f;
-                            wv[t].z = (gb + 2 < bs) ? win[gb + 2] : 0.0f;
-                            wv[t].w = (gb + 3 < bs) ? win[gb + 3] : 0.0f;
-                        }
-                    }
+                            for (int j = 0; j < MLO; ++j) wh[j] = (g0 - 1 - j >= 0) ? win[g0 - 1 - j] : 0.0f;
+                            double hist[MLO];  // hist[j] = d[i-1-j]
 #pragma unroll
-                    for (int j = 0; j < MLO; ++j) wh[j] = (g0 - 1 - j >= 0) ? win[g0 - 1 - j] : 0.0f;
-                    double hist[MLO];  // hist[j] = d[i-1-j]
+                            for (int j = 0; j < MLO; ++j) hist[j] = (double)smp[smp_idx(g0 - 1 - j)] * (double)wh[j];
 #pragma unroll
-                    for (int j = 0; j < MLO; ++j) hist[j] = (double)smp[cbase - kChunkStride + 63 - j] * (double)wh[j];
+                            for (int t = 0; t < 8; ++t) {
+                                int4 xv = *reinterpret_cast<const int4*>(&smp[pbase + 4 * t]);
+                                const int xs[4] = {xv.x, xv.y, xv.z, xv.w};
+                                const float ws[4] = {wv[t].x, wv[t].y, wv[t].z, wv[t].w};
 #pragma unroll
-                    for (int t = 0; t < 16; ++t) {
-                        int4 xv = *reinterpret_cast<const int4*>(&smp[cbase + 4 * t]);
-                        const int xs[4] = {xv.x, xv.y, xv.z, xv.w};
-                        const float ws[4] = {wv[t].x, wv[t].y, wv[t].z, wv[t].w};
+                                for (int e = 0; e < 4; ++e) {
+                                    // (a sample at or past bs has window 0: it adds exact zeros and leaves zero history)
+                                    const double d = (g0 + 4 * t + e < bs) ? (double)xs[e] * (double)ws[e] : 0.0;
+                                    acc[0] = __builtin_fma(d, d, acc[0]);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const double d = (double)xs[e] * (double)ws[e];
-                            acc[0] = __builtin_fma(d, d, acc[0]);
+                                    for (int j = 0; j < MLO; ++j) acc[j + 1] = __builtin_fma(d, hist[j], acc[j + 1]);
 #pragma unroll
-                            for (int j = 0; j < MLO; ++j) acc[j + 1] = __builtin_fma(d, hist[j], acc[j + 1]);
-#pragma unroll
-                            for (int j = MLO - 1; j > 0; --j) hist[j] = hist[j - 1];
-                            hist[0] = d;
+                                    for (int j = MLO - 1; j > 0; --j) hist[j] = hist[j - 1];
+                                    hist[0] = d;
+                                }
+                            }
                         }
                     }
                 }

@@ -22,6 +22,7 @@
 #define FA_HAVE_K5_LAUNCHERS 1  // single-unit build: the K5 kernels and their launchers live here
 #endif
 #include "encode_kernels.hpp"
+#include "encode_fused.hpp"
 #include "quantize_kernels.hpp"
 
 namespace {
@@ -45,7 +46,8 @@ struct DeviceState {
     std::recursive_mutex api_mu;
     std::map<int, float*> windows;  // blocksize -> device tukey(0.5) table
     uint16_t* crc_tab = nullptr;
-    void* scratch[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint16_t* crc_tab_fused = nullptr;
+    void* scratch[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [10]: K1a partial ranges
     size_t scratch_bytes[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t scratch_epoch = 1;  // bumped whenever a scratch slot is (re)allocated or released: cached contents are then stale
     // frame-header table of the most recent encode geometry (host copy + what the device copy was built from)
@@ -188,6 +190,53 @@ int get_crc_tab(const uint16_t** out) {
     return FA_ERROR_NONE;
 }
 
+// CRC-16 tables of the single-pass encoder (encode_fused.hpp): four slicing tables pre-multiplied by x^2016, so that
+// XORing a lane's running state into the top half of its next word (256 bytes further on) advances it for free,
+// followed by xpow[i] = x^(8 (i - 255)) mod P for the final per-lane alignment (negative powers through the order of
+// x^8 in GF(2)[x] / P, found by iteration).
+int get_crc_tab_fused(const uint16_t** out) {
+    DeviceState* st = dev_state();
+    if (!st) return FA_ERROR_DEVICE;
+    if (!st->crc_tab_fused) {
+        std::vector<uint16_t> t((size_t)(kFCrcSlice + kFCrcXpow));
+        auto mulx8 = [](uint16_t c) { return crc16_byte(c, 0); };
+        auto mulmod = [](uint16_t a, uint16_t b) {
+            uint32_t r = 0;
+            for (int i = 15; i >= 0; --i) {
+                r = (r << 1) ^ ((r & 0x8000u) ? 0x18005u : 0u);
+                if ((b >> i) & 1) r ^= a;
+            }
+            return (uint16_t)r;
+        };
+        int ord = 0;
+        for (uint16_t c = 1;;) { c = mulx8(c); ++ord; if (c == 1) break; }
+        auto xpow8 = [&](long k) {  // x^(8k) mod P for any integer k
+            k %= ord;
+            if (k < 0) k += ord;
+            uint16_t c = 1;
+            for (long i = 0; i < k; ++i) c = mulx8(c);
+            return c;
+        };
+        const uint16_t x2016 = xpow8(252);
+        for (int k = 0; k < 4; ++k)
+            for (int v = 0; v < 256; ++v) {
+                uint16_t c = 0;
+                for (int b = 0; b < 4; ++b) c = crc16_byte(c, (uint8_t)(b == k ? v : 0));
+                t[(size_t)(k * 256 + v)] = mulmod(c, x2016);
+            }
+        {
+            uint16_t c = xpow8(-255);
+            for (int i = 0; i < kFCrcXpow; ++i) { t[(size_t)(kFCrcSlice + i)] = c; c = mulx8(c); }
+        }
+        uint16_t* d = nullptr;
+        FA_HIP_TRY(hipMalloc(&d, sizeof(uint16_t) * t.size()));
+        FA_HIP_TRY(hipMemcpy(d, t.data(), sizeof(uint16_t) * t.size(), hipMemcpyHostToDevice));
+        st->crc_tab_fused = d;
+    }
+    *out = st->crc_tab_fused;
+    return FA_ERROR_NONE;
+}
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct EncodePlan {
@@ -223,6 +272,46 @@ int make_plan(int64_t n_stream, int64_t stream_size, uint32_t level, EncodePlan*
 template <int MLO, int NCH>
 void launch_encode(const EncodeArgs& a, int64_t F, hipStream_t st) {
     hipLaunchKernelGGL((encode_frames_kernel<MLO, NCH>), dim3((unsigned)F), dim3(64), 0, st, a);
+}
+
+// ---- single-pass encode (encode_fused.hpp): every frame is a full 4096-sample mono frame ----
+struct FusedPlan {
+    LevelParams P;
+    int64_t nf, F, hb;
+    size_t off_fbytes, off_fabs, off_zero, off_size, off_off, off_ticket, zero_bytes, off_total, total;
+    int64_t capacity;
+};
+
+bool fused_geometry(int64_t n_stream, int64_t stream_size, uint32_t level) {
+    if (level < 3 || level > 8 || n_stream <= 0 || stream_size <= 0) return false;
+    if (stream_size % kMaxBlock != 0) return false;
+    const int64_t nf = stream_size / kMaxBlock;
+    if (18 * nf >= (1 << 24)) return false;
+    if (nf > 0x7fffffffLL / n_stream) return false;
+    return std::getenv("FLACARRAY_HIP_SLOTS") == nullptr;  // diagnostic: force the slot path (K3 + K4 + K5)
+}
+
+void make_fused_plan(int64_t n_stream, int64_t stream_size, uint32_t level, FusedPlan* pl) {
+    pl->P = level_params(level);
+    pl->nf = stream_size / kMaxBlock;
+    pl->F = n_stream * pl->nf;
+    pl->hb = stream_header_bytes(pl->nf);
+    size_t o = 0;
+    pl->off_fbytes = o; o = align_up(o + (size_t)pl->F * 4, 256);
+    pl->off_fabs = o;   o = align_up(o + (size_t)pl->F * 8, 256);
+    pl->off_zero = o;   // everything from here to off_total is zeroed before every launch
+    pl->off_size = o;   o = align_up(o + (size_t)pl->F * 4, 256);
+    pl->off_off = o;    o = align_up(o + (size_t)pl->F * 8, 256);
+    pl->off_ticket = o; o = align_up(o + 16, 256);  // ticket word, error flags
+    pl->zero_bytes = o - pl->off_zero;
+    pl->off_total = o;  o = align_up(o + 8, 256);
+    pl->total = o;
+    pl->capacity = pl->F * (int64_t)kSlotBytes + n_stream * pl->hb;
+}
+
+template <int MLO, bool F32IN>
+void launch_fused(const FusedArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL((encode_fused_kernel<MLO, F32IN>), dim3((unsigned)((a.total_frames + kFWaves - 1) / kFWaves) + 1u), dim3(64 * kFWaves), 0, st, a);  // + the scanner's workgroup
 }
 
 int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int64_t* d_starts, const int64_t* d_nbytes,
@@ -332,6 +421,7 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
     if (a.B > kMaxBlock * 16) return FA_ERROR_DECODE_INIT;
     const unsigned nblk = (unsigned)((a.n_tasks + 63) / 64);
     const bool f32 = (d_out_f32 != nullptr);
+#ifndef FA_DEV_MINIMAL
     if (nch == 2) {
         // two-channel arrays: task-local planar image (low words), bit 32 of every sample, task status
         a.hib_words = (a.B + 31) / 32;
@@ -364,7 +454,17 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
         FA_HIP_TRY(hipGetLastError());
         return h_err[0];
     }
+#endif
     prof_begin(2, st);
+#ifdef FA_DEV_MINIMAL
+    (void)f32;
+    hipLaunchKernelGGL((decode_frames_kernel<8, -1, false, 1>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
+    prof_end(2, st);
+    prof_end(4, st);
+    FA_HIP_TRY(hipMemcpyAsync(h_err, d_err, 16, hipMemcpyDeviceToHost, st));
+    FA_HIP_TRY(hipStreamSynchronize(st));
+    return h_err[0] | (h_err[1] ? FA_ERROR_DECODE_PROCESS : 0);
+#else
     if (f32) hipLaunchKernelGGL((decode_frames_kernel<8, -1, true, 1>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
     else hipLaunchKernelGGL((decode_frames_kernel<8, -1, false, 1>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
     prof_end(2, st);
@@ -385,6 +485,7 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
     }
     FA_HIP_TRY(hipGetLastError());
     return h_err[0];
+#endif
 }
 
 int validate_range(int64_t stream_size, int64_t first_sample, int64_t last_sample, int64_t* first_decode, int64_t* n_decode) {
@@ -519,6 +620,9 @@ static int encode_device_begin(const int32_t* d_data, int nch, int64_t n_stream,
     }
 #endif
     prof_begin(0, st);
+#ifdef FA_DEV_MINIMAL  // diagnostic builds (seconds instead of minutes to compile): level 3-5 int32 kernels only
+    launch_encode<8, 1>(a, pl.F, st);
+#else
     if (nch == 1) {
         switch (a.max_lpc_order) {
             case 0: launch_encode<0, 1>(a, pl.F, st); break;
@@ -534,6 +638,7 @@ static int encode_device_begin(const int32_t* d_data, int nch, int64_t n_stream,
             default: launch_encode<12, 2>(a, pl.F, st); break;
         }
     }
+#endif
     prof_end(0, st);
     int64_t* d_foff = reinterpret_cast<int64_t*>(ws + pl.off_foff);
     int64_t* d_snb = reinterpret_cast<int64_t*>(ws + pl.off_snb);
@@ -598,6 +703,174 @@ int fa_encode_i32_device_finish(int64_t n_stream, int64_t stream_size, uint32_t 
 int fa_encode_i64_device_finish(int64_t n_stream, int64_t stream_size, uint32_t level, void* d_workspace,
                                 const int64_t* d_starts, unsigned char* d_bytes, void* stream) {
     return encode_device_finish(2, n_stream, stream_size, level, d_workspace, d_starts, d_bytes, stream);
+}
+
+int fa_encode_single_pass_supported(int64_t n_stream, int64_t stream_size, uint32_t level) {
+    return fused_geometry(n_stream, stream_size, level) ? 1 : 0;
+}
+
+int64_t fa_encode_capacity_bytes(int64_t n_stream, int64_t stream_size, uint32_t level) {
+    if (level > 8 || n_stream <= 0 || stream_size <= 0) return -1;
+    if (fused_geometry(n_stream, stream_size, level)) {
+        FusedPlan pl;
+        make_fused_plan(n_stream, stream_size, level, &pl);
+        return pl.capacity;
+    }
+    EncodePlan pl;
+    if (make_plan(n_stream, stream_size, level, &pl) != FA_ERROR_NONE) return -1;
+    return pl.F * (int64_t)kSlotBytes + n_stream * stream_header_bytes(pl.nf);
+}
+
+int64_t fa_encode_single_pass_workspace_bytes(int64_t n_stream, int64_t stream_size, uint32_t level) {
+    if (fused_geometry(n_stream, stream_size, level)) {
+        FusedPlan pl;
+        make_fused_plan(n_stream, stream_size, level, &pl);
+        return (int64_t)pl.total;
+    }
+    return fa_encode_workspace_bytes(n_stream, stream_size, level);
+}
+
+// the single-pass sequence: (float32 input: range pre-pass K1a/K1b,) zero the publish words, K3F, stream headers
+static int fused_encode_run(const void* d_data, bool f32, const float* d_quanta, float* d_offsets, float* d_gains, int64_t n_stream,
+                            int64_t stream_size, uint32_t level, void* d_workspace, int64_t workspace_bytes, unsigned char* d_bytes,
+                            int64_t capacity_bytes, int64_t* d_starts, int64_t* d_nbytes, int64_t* h_total_bytes, int32_t* d_info,
+                            void* stream) {
+    FA_API_LOCK;
+    FusedPlan pl;
+    make_fused_plan(n_stream, stream_size, level, &pl);
+    if (!d_workspace || workspace_bytes < (int64_t)pl.total) return FA_ERROR_ALLOC;
+    if (!d_bytes || capacity_bytes < pl.capacity) return FA_ERROR_ALLOC;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    char* ws = reinterpret_cast<char*>(d_workspace);
+    prof_begin(3, st);
+    int* d_nanflag = reinterpret_cast<int*>(ws + pl.off_ticket + 12);  // (inside the zeroed region)
+    FA_HIP_TRY(hipMemsetAsync(ws + pl.off_zero, 0, pl.zero_bytes, st));
+    if (f32) {
+        const int64_t cps = (stream_size + kRangeChunk - 1) / kRangeChunk;
+        void* pp = nullptr;
+        int rcp = get_scratch(10, (size_t)n_stream * (size_t)cps * 8 + 256, &pp);
+        if (rcp) return rcp;
+        float* pmin = reinterpret_cast<float*>(pp);
+        float* pmax = pmin + n_stream * cps;
+        prof_begin(5, st);
+        hipLaunchKernelGGL(float32_range_kernel, dim3((unsigned)(n_stream * cps)), dim3(256), 0, st, reinterpret_cast<const float*>(d_data),
+                           stream_size, cps, pmin, pmax, d_nanflag);
+        hipLaunchKernelGGL(float32_params_kernel, dim3((unsigned)((n_stream + 255) / 256)), dim3(256), 0, st, pmin, pmax, n_stream, cps,
+                           d_quanta, d_offsets, d_gains);
+        prof_end(5, st);
+    }
+    FusedArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.data = reinterpret_cast<const int32_t*>(d_data); a.f_offsets = d_offsets; a.f_gains = d_gains; a.n_stream = n_stream; a.stream_size = stream_size; a.nframes = pl.nf; a.total_frames = pl.F;
+    a.max_lpc_order = pl.P.max_lpc_order; a.max_porder = pl.P.max_porder; a.precision = pl.P.qlp_precision;
+    a.pmax_full = max_porder_for(kMaxBlock, a.max_porder, 0);
+    a.escale_full = 0.5 / (double)kMaxBlock;
+    int rc = get_window(kMaxBlock, &a.win);
+    if (rc) return rc;
+    rc = get_crc_tab_fused(&a.crc_tab);
+    if (rc) return rc;
+    {
+        void* dp = nullptr;
+        rc = get_scratch(9, (size_t)pl.nf * sizeof(uint4) + 256, &dp);
+        if (rc) return rc;
+        if (ds_->c_nf != pl.nf || ds_->c_B != kMaxBlock || ds_->c_tail != kMaxBlock || ds_->c_nch != 1 || ds_->c_dp != dp ||
+            ds_->c_epoch != ds_->scratch_epoch) {
+            ds_->h_hdr.resize((size_t)pl.nf);
+            for (int64_t f = 0; f < pl.nf; ++f) ds_->h_hdr[(size_t)f] = frame_header_entry((uint64_t)f, kMaxBlock, 1);
+            FA_HIP_TRY(hipMemcpyAsync(dp, ds_->h_hdr.data(), (size_t)pl.nf * sizeof(uint4), hipMemcpyHostToDevice, st));
+            FA_HIP_TRY(hipStreamSynchronize(st));
+            ds_->c_nf = pl.nf; ds_->c_B = kMaxBlock; ds_->c_tail = kMaxBlock; ds_->c_nch = 1; ds_->c_dp = dp; ds_->c_epoch = ds_->scratch_epoch;
+        }
+        a.hdr = reinterpret_cast<const uint4*>(dp);
+    }
+    a.blob = d_bytes; a.capacity = capacity_bytes; a.hb = pl.hb;
+    a.frame_bytes = reinterpret_cast<uint32_t*>(ws + pl.off_fbytes);
+    a.frame_abs = reinterpret_cast<int64_t*>(ws + pl.off_fabs);
+    a.info = reinterpret_cast<FrameInfo*>(d_info);
+    a.size_pub = reinterpret_cast<uint32_t*>(ws + pl.off_size);
+    a.off_pub = reinterpret_cast<unsigned long long*>(ws + pl.off_off);
+    a.total = reinterpret_cast<int64_t*>(ws + pl.off_total);
+    a.ticket = reinterpret_cast<uint32_t*>(ws + pl.off_ticket);
+    a.err = reinterpret_cast<int*>(ws + pl.off_ticket + 8);
+#ifdef FA_STAMPS
+    {
+        void* sp = nullptr;
+        if (get_scratch(6, 256, &sp) == 0) {
+            if (!ds_->stamps_zeroed) { (void)hipMemset(sp, 0, 256); ds_->stamps_zeroed = true; }
+            a.stamps = reinterpret_cast<unsigned long long*>(sp);
+        }
+    }
+#endif
+    prof_begin(0, st);
+#ifdef FA_DEV_MINIMAL
+    if (f32) launch_fused<8, true>(a, st);
+    else launch_fused<8, false>(a, st);
+#else
+    if (f32) {
+        switch (a.max_lpc_order) {
+            case 6: launch_fused<6, true>(a, st); break;
+            case 8: launch_fused<8, true>(a, st); break;
+            default: launch_fused<12, true>(a, st); break;
+        }
+    } else {
+        switch (a.max_lpc_order) {
+            case 6: launch_fused<6, false>(a, st); break;
+            case 8: launch_fused<8, false>(a, st); break;
+            default: launch_fused<12, false>(a, st); break;
+        }
+    }
+#endif
+    prof_end(0, st);
+    int64_t* d_total = reinterpret_cast<int64_t*>(ws + pl.off_total);
+    hipLaunchKernelGGL(fused_finish_kernel, dim3((unsigned)n_stream), dim3(256), 0, st, d_bytes, a.frame_abs, a.frame_bytes, n_stream,
+                       pl.nf, stream_size, (int32_t)kMaxBlock, (int32_t)kMaxBlock, 1, pl.hb, d_starts, d_nbytes, d_total);
+    prof_end(3, st);
+    int h_err = 0, h_nan = 0;
+    FA_HIP_TRY(hipMemcpyAsync(&h_err, a.err, 4, hipMemcpyDeviceToHost, st));
+    FA_HIP_TRY(hipMemcpyAsync(&h_nan, d_nanflag, 4, hipMemcpyDeviceToHost, st));
+    FA_HIP_TRY(hipMemcpyAsync(h_total_bytes, d_total, 8, hipMemcpyDeviceToHost, st));
+    FA_HIP_TRY(hipStreamSynchronize(st));
+    FA_HIP_TRY(hipGetLastError());
+    if (h_nan & 1) return FA_ERROR_NAN_INPUT;
+    if (h_err) {
+        std::fprintf(stderr, "flacarray_hip: single-pass encode failed (flags %d: 1 = offset outside the buffer, 2 = a frame timed out waiting for its offset, 4 = the scanner timed out)\n", h_err);
+        return FA_ERROR_ENCODE_PROCESS;
+    }
+    return FA_ERROR_NONE;
+}
+
+
+int fa_encode_i32_device(const int32_t* d_data, int64_t n_stream, int64_t stream_size, uint32_t level, void* d_workspace,
+                         int64_t workspace_bytes, unsigned char* d_bytes, int64_t capacity_bytes, int64_t* d_starts,
+                         int64_t* d_nbytes, int64_t* h_total_bytes, int32_t* d_info, void* stream) {
+    if (level > 8) return FA_ERROR_INVALID_LEVEL;
+    if (n_stream <= 0) return FA_ERROR_ZERO_NSTREAM;
+    if (stream_size <= 0) return FA_ERROR_ZERO_STREAMSIZE;
+    if (!fused_geometry(n_stream, stream_size, level) || (reinterpret_cast<uintptr_t>(d_data) & 15)) {
+        // frames the single-pass kernel does not cover (short blocks of levels 0-2, tail frames, unaligned rows):
+        // the slot path, into the same caller-provided buffer
+        int rc = encode_device_begin(d_data, 1, n_stream, stream_size, level, d_workspace, workspace_bytes, d_starts, d_nbytes,
+                                     h_total_bytes, d_info, stream);
+        if (rc) return rc;
+        if (*h_total_bytes > capacity_bytes) return FA_ERROR_ALLOC;
+        return encode_device_finish(1, n_stream, stream_size, level, d_workspace, d_starts, d_bytes, stream);
+    }
+    return fused_encode_run(d_data, false, nullptr, nullptr, nullptr, n_stream, stream_size, level, d_workspace, workspace_bytes, d_bytes,
+                            capacity_bytes, d_starts, d_nbytes, h_total_bytes, d_info, stream);
+}
+
+int fa_encode_f32_device(const float* d_data, int64_t n_stream, int64_t stream_size, uint32_t level, const float* d_quanta,
+                         void* d_workspace, int64_t workspace_bytes, unsigned char* d_bytes, int64_t capacity_bytes,
+                         int64_t* d_starts, int64_t* d_nbytes, float* d_offsets, float* d_gains, int64_t* h_total_bytes,
+                         int32_t* d_info, void* stream) {
+    if (level > 8) return FA_ERROR_INVALID_LEVEL;
+    if (n_stream <= 0) return FA_ERROR_ZERO_NSTREAM;
+    if (stream_size <= 0) return FA_ERROR_ZERO_STREAMSIZE;
+    if (!d_offsets || !d_gains) return FA_ERROR_CONVERT_TYPE;
+    // (other geometries: quantise with fa_float32_to_int32_device, then encode the integers)
+    if (!fused_geometry(n_stream, stream_size, level) || (reinterpret_cast<uintptr_t>(d_data) & 15)) return FA_ERROR_ENCODE_INIT;
+    return fused_encode_run(d_data, true, d_quanta, d_offsets, d_gains, n_stream, stream_size, level, d_workspace, workspace_bytes, d_bytes,
+                            capacity_bytes, d_starts, d_nbytes, h_total_bytes, d_info, stream);
 }
 
 int fa_decode_i32_device(const unsigned char* d_bytes, int64_t n_bytes, const int64_t* d_starts,
@@ -765,7 +1038,8 @@ static int encode_host(const int32_t* data, int nch, int64_t n_stream, int64_t s
     int err = FA_ERROR_NONE;
     for (int64_t s0 = 0; s0 < n_stream && !err; s0 += chunk) {
         const int64_t ns = (n_stream - s0 < chunk) ? (n_stream - s0) : chunk;
-        const int64_t wsb = (nch == 2) ? fa_encode_workspace_bytes_i64(ns, stream_size, level) : fa_encode_workspace_bytes(ns, stream_size, level);
+        const int64_t wsb = (nch == 2) ? fa_encode_workspace_bytes_i64(ns, stream_size, level)
+                                       : fa_encode_single_pass_workspace_bytes(ns, stream_size, level);  // (the slot path's size when that runs)
         void *d_in = nullptr, *d_ws = nullptr, *d_aux = nullptr, *d_out = nullptr;
         const size_t in_b = (size_t)ns * (size_t)stream_size * 4 * (size_t)nch;
         if ((err = get_scratch(0, in_b, &d_in))) break;
@@ -775,11 +1049,19 @@ static int encode_host(const int32_t* data, int nch, int64_t n_stream, int64_t s
         int64_t* d_nb = d_starts + ns;
         if (hipMemcpy(d_in, data + s0 * stream_size * nch, in_b, hipMemcpyHostToDevice) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
         int64_t total = 0;
-        err = encode_device_begin(reinterpret_cast<const int32_t*>(d_in), nch, ns, stream_size, level, d_ws, wsb, d_starts, d_nb, &total, nullptr, nullptr);
-        if (err) break;
-        if ((err = get_scratch(3, (size_t)total + 256, &d_out))) break;
-        err = encode_device_finish(nch, ns, stream_size, level, d_ws, d_starts, reinterpret_cast<unsigned char*>(d_out), nullptr);
-        if (err) break;
+        if (nch == 1 && fused_geometry(ns, stream_size, level)) {
+            const int64_t cap = fa_encode_capacity_bytes(ns, stream_size, level);
+            if ((err = get_scratch(3, (size_t)cap + 256, &d_out))) break;
+            err = fa_encode_i32_device(reinterpret_cast<const int32_t*>(d_in), ns, stream_size, level, d_ws, wsb,
+                                       reinterpret_cast<unsigned char*>(d_out), cap, d_starts, d_nb, &total, nullptr, nullptr);
+            if (err) break;
+        } else {
+            err = encode_device_begin(reinterpret_cast<const int32_t*>(d_in), nch, ns, stream_size, level, d_ws, wsb, d_starts, d_nb, &total, nullptr, nullptr);
+            if (err) break;
+            if ((err = get_scratch(3, (size_t)total + 256, &d_out))) break;
+            err = encode_device_finish(nch, ns, stream_size, level, d_ws, d_starts, reinterpret_cast<unsigned char*>(d_out), nullptr);
+            if (err) break;
+        }
         unsigned char* hp = reinterpret_cast<unsigned char*>(std::malloc((size_t)total > 0 ? (size_t)total : 1));
         if (!hp) { err = FA_ERROR_ALLOC; break; }
         parts.push_back(hp);

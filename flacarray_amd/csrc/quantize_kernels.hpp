@@ -111,6 +111,90 @@ __global__ __launch_bounds__(1024) void float32_to_int32_kernel(const float* __r
     }
 }
 
+// ---- float32 input fused into the encoder (encode_fused.hpp, F32IN): only the per-stream range is needed up front ----
+// K1a: grid = n_stream x chunks, one 256-thread block per chunk of up to kRangeChunk samples: min / max / NaN of the chunk.
+// K1b: one thread per stream folds the chunk results into offset and gain, with exactly the arithmetic of K1 / utils.c:194-230.
+// The samples are then quantised where the encoder loads them (quantise_f32): 4 B per sample read once more, nothing written.
+constexpr int kRangeChunk = 65536;
+__global__ __launch_bounds__(256) void float32_range_kernel(const float* __restrict__ input, int64_t stream_size, int64_t chunks_per_stream,
+                                                            float* __restrict__ part_min, float* __restrict__ part_max,
+                                                            int* __restrict__ flags) {
+    __shared__ float s_min[4], s_max[4];
+    const int64_t is = blockIdx.x / chunks_per_stream;
+    const int64_t ck = blockIdx.x - is * chunks_per_stream;
+    const int64_t lo = ck * kRangeChunk;
+    int64_t hi = lo + kRangeChunk;
+    if (hi > stream_size) hi = stream_size;
+    const float* in = input + is * stream_size + lo;
+    const int tid = threadIdx.x;
+    float mn = in[0], mx = in[0];
+    bool nan = false;
+    const bool vec = ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
+    const int64_t n = hi - lo;
+    const int64_t n4 = vec ? (n >> 2) : 0;
+    for (int64_t i = tid; i < n4; i += 256) {
+        const float4 v = reinterpret_cast<const float4*>(in)[i];
+        nan = nan || (v.x != v.x) || (v.y != v.y) || (v.z != v.z) || (v.w != v.w);
+        mn = (v.x < mn) ? v.x : mn; mx = (v.x > mx) ? v.x : mx;
+        mn = (v.y < mn) ? v.y : mn; mx = (v.y > mx) ? v.y : mx;
+        mn = (v.z < mn) ? v.z : mn; mx = (v.z > mx) ? v.z : mx;
+        mn = (v.w < mn) ? v.w : mn; mx = (v.w > mx) ? v.w : mx;
+    }
+    for (int64_t i = 4 * n4 + tid; i < n; i += 256) {
+        const float v = in[i];
+        nan = nan || (v != v);
+        mn = (v < mn) ? v : mn;
+        mx = (v > mx) ? v : mx;
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float a = __shfl_xor(mn, off, 64), b = __shfl_xor(mx, off, 64);
+        mn = (a < mn) ? a : mn;
+        mx = (b > mx) ? b : mx;
+    }
+    if (__any(nan) && (tid & 63) == 0) atomicOr(flags, 1);
+    if ((tid & 63) == 0) { s_min[tid >> 6] = mn; s_max[tid >> 6] = mx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) {
+            mn = (s_min[w] < mn) ? s_min[w] : mn;
+            mx = (s_max[w] > mx) ? s_max[w] : mx;
+        }
+        part_min[blockIdx.x] = mn;
+        part_max[blockIdx.x] = mx;
+    }
+}
+
+__global__ __launch_bounds__(256) void float32_params_kernel(const float* __restrict__ part_min, const float* __restrict__ part_max,
+                                                             int64_t n_stream, int64_t chunks_per_stream, const float* __restrict__ quanta,
+                                                             float* __restrict__ offsets, float* __restrict__ gains) {
+    const int64_t is = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (is >= n_stream) return;
+    float smin = part_min[is * chunks_per_stream], smax = part_max[is * chunks_per_stream];
+    for (int64_t c = 1; c < chunks_per_stream; ++c) {
+        const float a = part_min[is * chunks_per_stream + c], b = part_max[is * chunks_per_stream + c];
+        smin = (a < smin) ? a : smin;
+        smax = (b > smax) ? b : smax;
+    }
+    float off = (float)(0.5 * (double)__fadd_rn(smin, smax));                    // utils.c:194
+    const float d1 = __fsub_rn(smin, off), d2 = __fsub_rn(smax, off);
+    const float amp = (d1 > d2) ? (float)(1.01 * (double)d1) : (float)(1.01 * (double)d2);  // :198-202
+    const float min_quanta = __fdiv_rn(amp, 2147483648.0f);                      // :203
+    const float sq = quanta ? quanta[is] : min_quanta;
+    const int64_t nquant = x86_cvtt_i64((double)off / (double)sq);                // :221
+    off = (float)((double)sq * (double)nquant);                                   // :222
+    offsets[is] = off;
+    gains[is] = (sq == 0.0f) ? 1.0f : (float)(1.0 / (double)sq);                  // :224-230
+}
+
+// one sample, utils.c:232-240: float subtract, float multiply, double +-0.5, truncation (x86 overflow behaviour)
+__device__ __forceinline__ int32_t quantise_f32(float x, float off, float gain) {
+    const float st = __fsub_rn(x, off);
+    const float pr = __fmul_rn(gain, st);
+    const double dv = (st >= 0.0f) ? (double)pr + 0.5 : (double)pr - 0.5;
+    return x86_cvtt_i32(dv);
+}
+
 // grid = (chunks per stream, n_stream folded into x); each block converts up to 16384 samples
 constexpr int kDequantChunk = 16384;
 __global__ __launch_bounds__(256) void int32_to_float32_kernel(const int32_t* __restrict__ input, int64_t stream_size,

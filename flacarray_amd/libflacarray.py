@@ -244,12 +244,17 @@ class EncodeWorkspace:
         return self.buf
 
 
-def encode_flac_device(data, level=5, workspace=None, return_info=False):
+def encode_flac_device(data, level=5, workspace=None, return_info=False, compact=False):
     """Encode a C-contiguous int32 (or int64: two-channel streams) CUDA tensor [..., stream_size] held in HBM.
 
     Returns (compressed uint8 tensor, starts int64 tensor, nbytes int64 tensor), all on the
     device, starts/nbytes with the leading shape of `data` (at least 1-D) -- the device-resident
     analogue of encode_flac (libflacarray.pyx:529-594).
+
+    int32 input whose stream length is a multiple of 4096 (levels 3-8) takes the single-pass kernel: the frames are
+    written straight to their final offsets inside a buffer sized for the worst case, and `compressed` is the view
+    [0, total) of that buffer (it keeps the whole buffer alive; `compact=True` returns an exact-size copy instead).
+    Everything else runs the slot sequence (K3, K4, K5) and returns an exact-size tensor.
     """
     torch = _torch()
     if data.dtype != torch.int32 and data.dtype != torch.int64:
@@ -268,12 +273,8 @@ def encode_flac_device(data, level=5, workspace=None, return_info=False):
         n_stream = int(np.prod(data.shape[:-1]))
         starts_shape = tuple(data.shape[:-1])
     L = _lib.lib()
-    ws_bytes = (L.fa_encode_workspace_bytes_i64 if i64 else L.fa_encode_workspace_bytes)(n_stream, stream_size, level)
-    if ws_bytes < 0:
-        raise RuntimeError("Encoding failed, return code = 512")
     if workspace is None:
         workspace = EncodeWorkspace()
-    ws = workspace.get(ws_bytes, data.device)
     starts = torch.empty(n_stream, dtype=torch.int64, device=data.device)
     nbytes = torch.empty(n_stream, dtype=torch.int64, device=data.device)
     info = None
@@ -282,6 +283,26 @@ def encode_flac_device(data, level=5, workspace=None, return_info=False):
         nf = (stream_size + bs - 1) // bs
         info = torch.zeros((n_stream * nf * (2 if i64 else 1), 8), dtype=torch.int32, device=data.device)
     total = ctypes.c_int64(0)
+    if not i64 and data.data_ptr() % 16 == 0 and L.fa_encode_single_pass_supported(n_stream, stream_size, level):
+        cap = L.fa_encode_capacity_bytes(n_stream, stream_size, level)
+        ws = workspace.get(L.fa_encode_single_pass_workspace_bytes(n_stream, stream_size, level), data.device)
+        with torch.cuda.device(data.device):
+            buf = torch.empty(cap, dtype=torch.uint8, device=data.device)
+            errcode = L.fa_encode_i32_device(
+                _dp(data), n_stream, stream_size, level, _dp(ws), ws.numel(), _dp(buf), cap, _dp(starts), _dp(nbytes),
+                ctypes.byref(total), _dp(info), _stream_ptr(),
+            )
+        if errcode != 0:
+            raise RuntimeError(f"Encoding failed, return code = {errcode}")
+        compressed = buf[: total.value]
+        if compact:
+            compressed = compressed.clone()
+        out = (compressed, starts.reshape(starts_shape), nbytes.reshape(starts_shape))
+        return out + (info,) if return_info else out
+    ws_bytes = (L.fa_encode_workspace_bytes_i64 if i64 else L.fa_encode_workspace_bytes)(n_stream, stream_size, level)
+    if ws_bytes < 0:
+        raise RuntimeError("Encoding failed, return code = 512")
+    ws = workspace.get(ws_bytes, data.device)
     with torch.cuda.device(data.device):
         errcode = (L.fa_encode_i64_device_begin if i64 else L.fa_encode_i32_device_begin)(
             _dp(data), n_stream, stream_size, level, _dp(ws), ws.numel(), _dp(starts), _dp(nbytes), ctypes.byref(total),
@@ -297,6 +318,60 @@ def encode_flac_device(data, level=5, workspace=None, return_info=False):
     if return_info:
         return out + (info,)
     return out
+
+
+def encode_flac_device_f32(data, quanta=None, level=5, workspace=None, compact=False):
+    """Quantise and encode a C-contiguous float32 CUDA tensor [..., stream_size] held in HBM: the device-resident
+    analogue of array_compress on float32 input (compress.py:50-84 -> float_to_int + encode_flac).
+
+    `quanta`: None (per-stream quanta from the data range), or a tensor with one value per stream.  Returns
+    (compressed, starts, nbytes, offsets, gains), offsets / gains float32 with the leading shape of `data`.  Where
+    the single-pass kernel applies (levels 3-8, stream length a multiple of 4096) the quantisation happens in the
+    encoder's staging load after a range pre-pass -- the int32 array never exists in HBM; otherwise the two steps
+    run one after the other.  Same bytes, offsets and gains either way."""
+    torch = _torch()
+    if data.dtype != torch.float32 or not data.is_contiguous():
+        raise ValueError("Only float32 and float64 data are supported")
+    if not data.is_cuda:
+        raise RuntimeError("encode_flac_device_f32 needs a tensor on the GPU")
+    if level < 0 or level > 8:
+        raise RuntimeError("FLAC only supports compression levels 0-8")
+    stream_size = data.shape[-1]
+    lead = tuple(data.shape[:-1]) if data.dim() > 1 else (1,)
+    n_stream = int(np.prod(lead))
+    q = None
+    if quanta is not None:
+        q = quanta.to(device=data.device, dtype=torch.float32).reshape(-1).contiguous()
+        if q.numel() != n_stream:
+            raise RuntimeError("quanta must have one entry per stream")
+    L = _lib.lib()
+    if not (data.data_ptr() % 16 == 0 and L.fa_encode_single_pass_supported(n_stream, stream_size, level)):
+        ints, offsets, gains = float32_to_int32_device(data, q)
+        comp, st, nb = encode_flac_device(ints, level=level, workspace=workspace, compact=compact)
+        return comp, st, nb, offsets, gains
+    if workspace is None:
+        workspace = EncodeWorkspace()
+    starts = torch.empty(n_stream, dtype=torch.int64, device=data.device)
+    nbytes = torch.empty(n_stream, dtype=torch.int64, device=data.device)
+    offsets = torch.empty(n_stream, dtype=torch.float32, device=data.device)
+    gains = torch.empty(n_stream, dtype=torch.float32, device=data.device)
+    cap = L.fa_encode_capacity_bytes(n_stream, stream_size, level)
+    ws = workspace.get(L.fa_encode_single_pass_workspace_bytes(n_stream, stream_size, level), data.device)
+    total = ctypes.c_int64(0)
+    with torch.cuda.device(data.device):
+        buf = torch.empty(cap, dtype=torch.uint8, device=data.device)
+        errcode = L.fa_encode_f32_device(
+            _dp(data), n_stream, stream_size, level, _dp(q), _dp(ws), ws.numel(), _dp(buf), cap, _dp(starts), _dp(nbytes),
+            _dp(offsets), _dp(gains), ctypes.byref(total), None, _stream_ptr(),
+        )
+    if errcode & _lib.ERROR_NAN_INPUT:
+        raise RuntimeError("Cannot convert data with NaNs to integers")
+    if errcode != 0:
+        raise RuntimeError(f"Encoding failed, return code = {errcode}")
+    compressed = buf[: total.value]
+    if compact:
+        compressed = compressed.clone()
+    return compressed, starts.reshape(lead), nbytes.reshape(lead), offsets.reshape(lead), gains.reshape(lead)
 
 
 def decode_flac_device(compressed, starts, nbytes, stream_size, first_sample=-1, last_sample=-1, offsets=None, gains=None,

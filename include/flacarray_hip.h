@@ -107,6 +107,30 @@ int fa_encode_i32_device_begin(const int32_t* d_data, int64_t n_stream, int64_t 
 int fa_encode_i32_device_finish(int64_t n_stream, int64_t stream_size, uint32_t level, void* d_workspace,
                                 const int64_t* d_starts, unsigned char* d_bytes, void* stream);
 
+/* Single-pass encode.  When the geometry allows it (levels 3-8, stream_size a multiple of 4096, 16-byte aligned
+ * input: fa_encode_single_pass_supported) ONE kernel analyses every frame, sizes it, finds its byte offset by a
+ * look-back over the frames before it and writes it -- CRC-16 included -- to its final place in d_bytes; there is
+ * no per-frame slot and no compaction pass.  The caller provides d_bytes with fa_encode_capacity_bytes() bytes
+ * (worst case: every frame VERBATIM) and a workspace of fa_encode_single_pass_workspace_bytes(); the encoded
+ * triple is d_bytes[0, *h_total_bytes), d_starts, d_nbytes.  Other geometries run the begin/finish sequence into
+ * the same buffers.  Same bytes as begin + finish in every case. */
+int fa_encode_single_pass_supported(int64_t n_stream, int64_t stream_size, uint32_t level);
+int64_t fa_encode_capacity_bytes(int64_t n_stream, int64_t stream_size, uint32_t level);
+int64_t fa_encode_single_pass_workspace_bytes(int64_t n_stream, int64_t stream_size, uint32_t level);
+int fa_encode_i32_device(const int32_t* d_data, int64_t n_stream, int64_t stream_size, uint32_t level, void* d_workspace,
+                         int64_t workspace_bytes, unsigned char* d_bytes, int64_t capacity_bytes, int64_t* d_starts,
+                         int64_t* d_nbytes, int64_t* h_total_bytes, int32_t* d_info, void* stream);
+
+/* float32 input, quantisation fused into the single-pass encoder (float32_to_int32 of utils.c:160-243 without the
+ * int32 round trip through HBM): a range pre-pass writes d_offsets / d_gains[n_stream] (d_quanta may be NULL = per-stream
+ * quanta from the data range), then the encoder quantises every sample where it loads it.  Same bytes, offsets and
+ * gains as fa_float32_to_int32_device followed by fa_encode_i32_device.  Only for geometries the single-pass kernel
+ * covers (fa_encode_single_pass_supported); FA_ERROR_ENCODE_INIT otherwise, FA_ERROR_NAN_INPUT for a NaN. */
+int fa_encode_f32_device(const float* d_data, int64_t n_stream, int64_t stream_size, uint32_t level, const float* d_quanta,
+                         void* d_workspace, int64_t workspace_bytes, unsigned char* d_bytes, int64_t capacity_bytes,
+                         int64_t* d_starts, int64_t* d_nbytes, float* d_offsets, float* d_gains, int64_t* h_total_bytes,
+                         int32_t* d_info, void* stream);
+
 /* The same three calls for int64 input (two-channel streams); d_info, if given, holds one
  * FrameInfo per SUBFRAME: [ (stream * frames + frame) * 2 + channel ]. */
 int64_t fa_encode_workspace_bytes_i64(int64_t n_stream, int64_t stream_size, uint32_t level);

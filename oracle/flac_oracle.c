@@ -317,13 +317,18 @@ static void autocorr_lanes(const int32_t *x, const float *win, int bs, int nlag,
     static __thread double d[MAX_BLOCK];
     double part[64][MAX_ORDER + 1];
     for (int i = 0; i < bs; ++i) d[i] = (double)x[i] * (double)win[i];
+    /* partial sum l runs over samples [32 l, 32 l + 32) and then [2048 + 32 l, 2048 + 32 l + 32), as far as they lie
+     * below bs: the order in which the GPU kernels (one lane per partial sum, frame image split into two halves)
+     * accumulate.  Floating-point rounding makes this order part of the encoder specification. */
     for (int l = 0; l < 64; ++l) {
         for (int lag = 0; lag < nlag; ++lag) part[l][lag] = 0.0;
-        int hi = 64 * l + 64;
-        if (hi > bs) hi = bs;
-        for (int i = 64 * l; i < hi; ++i)
-            for (int lag = 0; lag < nlag; ++lag)
-                if (i >= lag) part[l][lag] = fma(d[i], d[i - lag], part[l][lag]);
+        for (int piece = 0; piece < 2; ++piece) {
+            int lo = 2048 * piece + 32 * l, hi = lo + 32;
+            if (hi > bs) hi = bs;
+            for (int i = lo; i < hi; ++i)
+                for (int lag = 0; lag < nlag; ++lag)
+                    if (i >= lag) part[l][lag] = fma(d[i], d[i - lag], part[l][lag]);
+        }
     }
     for (int off = 1; off < 64; off <<= 1) {
         for (int lag = 0; lag < nlag; ++lag) {

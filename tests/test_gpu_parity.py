@@ -51,6 +51,13 @@ CASES = [
     ("const", lambda: np.full((2, 4097), -77777, dtype=np.int32)),
     ("ramp", lambda: (np.arange(3 * 8192, dtype=np.int64).reshape(3, 8192) * 3 - 999).astype(np.int32)),
     ("spikes", lambda: _spikes()),
+    # whole frames only (the single-pass kernel's geometry): verbatim, wasted bits, constant, mixed frame types
+    ("fullrange2x8192", lambda: full_range_i32((2, 8192))),
+    ("wasted_whole_frames", lambda: (sinusoid_noise_i32(3, 8192, seed=6, amp=64) * 32).astype(np.int32)),
+    ("zeros_whole_frames", lambda: np.zeros((2, 8192), dtype=np.int32)),
+    ("const_then_noise", lambda: np.concatenate([np.full((3, 4096), 12345, np.int32), sinusoid_noise_i32(3, 8192, seed=2)], axis=1)),
+    ("walk_whole_frames", lambda: np.cumsum(np.random.default_rng(3).integers(-2000, 2001, size=(5, 16384)), axis=1).astype(np.int32)),
+    ("wide_5x12288", lambda: sinusoid_noise_i32(5, 12288, seed=13, amp=2**27)),
 ]
 
 
@@ -304,8 +311,9 @@ def test_cfg3_full_length_float(fa, oracle):
     n_ch, n = 1024, 1 << 20
     x = _make_float_field(torch, n_ch, n, 31337, dev)
     q = (2.0**-16 * (1 + torch.arange(n_ch, device=dev) % 4)).to(torch.float32)
-    ints, off, gain = fa.float32_to_int32_device(x, q)
-    comp, st, nb = fa.encode_flac_device(ints, level=5)
+    ints, off2, gain2 = fa.float32_to_int32_device(x, q)
+    comp, st, nb, off, gain = fa.encode_flac_device_f32(x, q, level=5)  # quantisation fused into the encoder's load
+    assert torch.equal(off, off2) and torch.equal(gain, gain2)
     y = fa.decode_flac_device(comp, st, nb, n, offsets=off, gains=gain)
     assert y.dtype == torch.float32 and y.shape == x.shape
     eps = float(np.finfo(np.float32).eps)
@@ -321,6 +329,60 @@ def test_cfg3_full_length_float(fa, oracle):
         assert np.array_equal(ints[c].cpu().numpy(), io.reshape(-1))
         assert offo.view(np.uint32)[0] == off[c : c + 1].cpu().numpy().view(np.uint32)[0]
         assert go.view(np.uint32)[0] == gain[c : c + 1].cpu().numpy().view(np.uint32)[0]
+
+
+def test_float_input_fused_into_the_encoder(fa, oracle):
+    """encode_flac_device_f32 (range pre-pass + quantisation in the single-pass encoder's staging load) gives the
+    bytes, offsets and gains of the two separate steps -- which are bit-equal to the oracle's float32_to_int32
+    (utils.c:160-243) followed by its encoder -- for explicit per-stream quanta and for quanta derived from the data."""
+    import torch
+
+    x = sinusoid_noise_f32(7, 3 * 4096, seed=23)
+    x[2] = 0.0          # all-zero stream: gain 1
+    x[3] += 10.51
+    x[5, :4096] = 3.25  # a constant frame inside a stream
+    q = (2.0**-16 * (1 + np.arange(7) % 4)).astype(np.float32)
+    d = torch.from_numpy(x).cuda()
+    for quanta in (q, None):
+        for level in (3, 5, 8):
+            io, offo, go = oracle.float32_to_int32(x, quanta)
+            blob_o, st_o, nb_o = oracle.encode_i32(io, level)
+            comp, st, nb, off, gain = fa.encode_flac_device_f32(d, None if quanta is None else torch.from_numpy(quanta), level=level)
+            assert np.array_equal(off.cpu().numpy().view(np.uint32), offo.view(np.uint32))
+            assert np.array_equal(gain.cpu().numpy().view(np.uint32), go.view(np.uint32))
+            assert np.array_equal(comp.cpu().numpy(), blob_o) and np.array_equal(st.cpu().numpy(), st_o) and np.array_equal(nb.cpu().numpy(), nb_o)
+            y = fa.decode_flac_device(comp, st, nb, x.shape[1], offsets=off, gains=gain)
+            assert np.array_equal(y.cpu().numpy().view(np.uint32), oracle.int32_to_float32(io, offo, go).view(np.uint32))
+    # a geometry the single-pass kernel does not take (tail frame): the two-step route, same contract
+    xs = x[:, :10000].copy()
+    io, offo, go = oracle.float32_to_int32(xs, q)
+    comp, st, nb, off, gain = fa.encode_flac_device_f32(torch.from_numpy(xs).cuda(), torch.from_numpy(q))
+    assert np.array_equal(comp.cpu().numpy(), oracle.encode_i32(io, 5)[0]) and np.array_equal(off.cpu().numpy().view(np.uint32), offo.view(np.uint32))
+    bad = x.copy()
+    bad[1, 5000] = np.nan
+    with pytest.raises(RuntimeError, match="NaNs"):
+        fa.encode_flac_device_f32(torch.from_numpy(bad).cuda(), torch.from_numpy(q))
+
+
+def test_single_pass_and_slot_sequence_write_the_same_bytes(fa):
+    """The single-pass kernel (K3F) and the slot sequence (K3 + K4 + K5, forced with FLACARRAY_HIP_SLOTS) are two
+    implementations of one specification: same blob, starts and nbytes on frames of every kind."""
+    import torch
+
+    x = np.concatenate(
+        [sinusoid_noise_i32(6, 8192, seed=71), full_range_i32((6, 4096)), np.zeros((6, 4096), np.int32),
+         (sinusoid_noise_i32(6, 4096, seed=72, amp=64) * 8).astype(np.int32)], axis=1)
+    d = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    for level in (3, 5, 7):
+        a = fa.encode_flac_device(d, level=level)
+        os.environ["FLACARRAY_HIP_SLOTS"] = "1"
+        try:
+            b = fa.encode_flac_device(d, level=level)
+        finally:
+            del os.environ["FLACARRAY_HIP_SLOTS"]
+        assert a[0].untyped_storage().size() > a[0].numel() == b[0].numel() == b[0].untyped_storage().size()  # a view of the capacity buffer vs an exact tensor
+        assert all(torch.equal(u, v) for u, v in zip(a, b))
+        assert torch.equal(fa.decode_flac_device(*a, x.shape[1]).cpu(), torch.from_numpy(x))
 
 
 def test_corrupt_index_rejected(fa, oracle):
@@ -832,4 +894,6 @@ def test_random_sweep_bytes_equal_oracle(fa, oracle, seed):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     bad, tot = mod.run(150, seed, verbose=False)
+    assert bad == 0 and tot > 0
+    bad, tot = mod.run(100, seed + 100, verbose=False, single_pass_only=True)  # geometries of the single-pass kernel only
     assert bad == 0 and tot > 0

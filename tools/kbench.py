@@ -51,7 +51,7 @@ def main():
     enc, cmp_, dec = res.mean(0)
     print(f"lib={os.path.basename(_lib.LIB_PATH)} ch={args.channels} c={c:.4f} B/sample")
     print(f"encode_frames {enc:8.3f} ms  {(4+c)*n/enc/1e6:8.1f} GB/s   compact {cmp_:7.3f} ms   decode_frames {dec:8.3f} ms  {(4+c)*n/dec/1e6:8.1f} GB/s")
-    if hasattr(L, "fa_debug_stamps") and "stamps" in _lib.LIB_PATH:
+    if hasattr(L, "fa_debug_stamps"):
         buf = (ctypes.c_ulonglong * 32)()
         L.fa_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
         L.fa_debug_stamps(buf, 1)
