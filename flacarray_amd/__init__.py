@@ -17,6 +17,7 @@ from .libflacarray import (
     encode_flac_device,
     encode_flac_device_f32,
     float32_to_int32_device,
+    set_decode_verify,
 )
 from .utils import float_to_int, int_to_float, keep_select
 
@@ -39,6 +40,7 @@ __all__ = [
     "decode_flac_device",
     "decode_slices_device",
     "float32_to_int32_device",
+    "set_decode_verify",
     "float_to_int",
     "int_to_float",
     "keep_select",

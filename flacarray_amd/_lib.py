@@ -40,6 +40,7 @@ SYMBOLS = [
     "fa_decode_slices_i64_device",
     "fa_float32_to_int32_device",
     "fa_int32_to_float32_device",
+    "fa_set_decode_verify",
     "fa_profile_enable",
     "fa_profile_last",
     "fa_profile_read",
@@ -110,6 +111,8 @@ def lib():
     L.fa_float32_to_int32_device.restype = cint
     L.fa_int32_to_float32_device.argtypes = [vp, i64, i64, vp, vp, vp, vp]
     L.fa_int32_to_float32_device.restype = cint
+    L.fa_set_decode_verify.argtypes = [cint]
+    L.fa_set_decode_verify.restype = cint
     L.fa_profile_enable.argtypes = [cint]
     L.fa_profile_enable.restype = None
     L.fa_profile_last.argtypes = [ctypes.POINTER(ctypes.c_float)]

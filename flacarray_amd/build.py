@@ -18,11 +18,13 @@ DEPS = [
     os.path.join(os.path.dirname(_HERE), "include", "flacarray_hip.h"),
 ]
 SRC_COMPACT = os.path.join(_HERE, "csrc", "compact_unit.hip")
-DEPS.append(SRC_COMPACT)
+SRC_FUSED = os.path.join(_HERE, "csrc", "fused_unit.hip")
+DEPS += [SRC_COMPACT, SRC_FUSED, os.path.join(_HERE, "csrc", "encode_fused.hpp"), os.path.join(_HERE, "csrc", "verify_kernels.hpp")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared"]
-# The shipped library is built from two translation units: the frame kernels (K3 encode, K7 decode) with LLVM's
-# max-ILP scheduling strategy (measured: K3 -4 %, K7 -2 %), the compaction kernels (K5) with the default one
-# (max-ILP slows K5 by 10 %).  Variants (diagnostic builds) stay single-unit, default strategy.
+# The shipped library is built from three translation units: the slot encoder and the decoder (K3, K7) with LLVM's
+# max-ILP scheduling strategy (measured: K3 -4 %, K7 -2 %), the compaction kernels (K5) and the single-pass encoder
+# (K3F, which has no registers to spare: 168 for three waves per SIMD) with the default one (max-ILP slows K5 by 10 %
+# and adds spills to K3F).  Variants (diagnostic builds) stay single-unit, default strategy.
 # K3's occupancy is two waves per SIMD by its LDS image, so the scheduler may as well use the 256 VGPRs (-1.5 %).
 MAIN_UNIT_FLAGS = [
     "-DFA_SPLIT_UNITS",
@@ -47,7 +49,7 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cflags = [f for f in FLAGS if f != "-shared"]
     objs, procs = [], []
-    for src, extra in ((SRC, MAIN_UNIT_FLAGS), (SRC_COMPACT, [])):  # the two units compile side by side
+    for src, extra in ((SRC, MAIN_UNIT_FLAGS), (SRC_COMPACT, []), (SRC_FUSED, [])):  # the units compile side by side
         obj = os.path.join(os.path.dirname(OUT), os.path.basename(src).replace(".hip", ".o"))
         cmd = [hipcc] + cflags + extra + ["-c", "-o", obj, src]
         if verbose:

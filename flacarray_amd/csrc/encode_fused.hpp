@@ -86,6 +86,11 @@ __device__ __forceinline__ int fsmp_idx(int s) {  // sample s of the first half 
     return fsmp_unit(c1, (s >> 2) & 7) + (s & 3);
 }
 
+__device__ __forceinline__ int lane_id_opaque() {  // the lane number, recomputed wherever it is asked for (two instructions)
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 __device__ __forceinline__ int dpp_wave_shr1(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x138, 0xF, 0xF, false); }
 
 __device__ __forceinline__ uint16_t crc16_mulmod(uint16_t a, uint16_t b) {  // a * b mod x^16 + x^15 + x^2 + 1
@@ -263,6 +268,7 @@ __device__ __forceinline__ void fused_scanner(const FusedArgs& a, int lane) {
     if (lane == 0) *a.total = (int64_t)(prefix + (uint64_t)a.n_stream * (uint64_t)a.hb);
 }
 
+#if defined(FA_UNIT_FUSED) || !defined(FA_SPLIT_UNITS)
 // ------------------------------------------------------------------------------------------
 // K3F
 // ------------------------------------------------------------------------------------------
@@ -314,9 +320,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
 
     // per-lane image addresses (words): K ^ (4 t) is unit t of the lane's own chunk A_l; rowbase + 256 j is the lane's
     // 4 samples of row j (row-major); hist7 / hist6 are the last two units of the chunk before A_l
-    const int K = fsmp_unit(lane + 1, 0);
-    const int rowbase = fsmp_unit((lane >> 3) + 1, lane & 7);
-    const int hist7 = fsmp_unit(lane, 7), hist6 = fsmp_unit(lane, 6), hist5 = fsmp_unit(lane, 5);
+    // They are re-derived from the lane number at the head of every phase (FA_IMAGE_ADDRS; the lane number through an
+    // opaque asm, so that the compiler cannot keep one copy alive -- and spill it -- across the whole kernel).
+#define FA_IMAGE_ADDRS                                                                  \
+    const int ln_ = lane_id_opaque();                                                   \
+    const int K = fsmp_unit(ln_ + 1, 0);                                                \
+    const int rowbase = fsmp_unit((ln_ >> 3) + 1, ln_ & 7);                             \
+    const int hist7 = fsmp_unit(ln_, 7), hist6 = fsmp_unit(ln_, 6), hist5 = fsmp_unit(ln_, 5); \
+    (void)K; (void)rowbase; (void)hist7; (void)hist6; (void)hist5
     constexpr int tailA7 = 32 * 64 + 4 * (7 ^ (64 & 7)), tailA6 = 32 * 64 + 4 * (6 ^ (64 & 7)), tailA5 = 32 * 64 + 4 * (5 ^ (64 & 7));
 
     FA_STAMP_INIT;
@@ -325,6 +336,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
     uint32_t orv = 0;
     int mn, mx;
     {
+        FA_IMAGE_ADDRS;
         int4 hi[8], lo[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) hi[j] = load_row(8 + j);
@@ -361,6 +373,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
     const int wasted = orv ? (__ffs((int)orv) - 1) : 0;
     const int bps = 32 - wasted;
     if (wasted) {
+        FA_IMAGE_ADDRS;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             Bv[t].x >>= wasted; Bv[t].y >>= wasted; Bv[t].z >>= wasted; Bv[t].w >>= wasted;
@@ -413,6 +426,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
         uint64_t hA0 = 0, hA1 = 0, hA2 = 0, hA3 = 0, hA4 = 0;
         double dA0 = 0.0, dA1 = 0.0, dA2 = 0.0, dA3 = 0.0, dA4 = 0.0;
         if (narrow) {
+            FA_IMAGE_ADDRS;
             const uint32_t BIAS = 0x80000000u;
             uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
             int p1, pe1, pe2, pe3;
@@ -472,6 +486,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
             fold();
             tot0 = (double)a0; tot1 = (double)a1; tot2 = (double)a2; tot3 = (double)a3; tot4 = (double)a4;
         } else {
+            FA_IMAGE_ADDRS;
             double p1, pe1, pe2, pe3;
             auto seed = [&](const int4& h) __attribute__((always_inline)) {
                 p1 = (double)h.w;
@@ -577,6 +592,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
         // ---- P3: LPC analysis ---------------------------------------------------------------------------
         int mlo = a.max_lpc_order;
         if (mlo > 0) {
+            FA_IMAGE_ADDRS;
             double acc[MLO + 1];
 #pragma unroll
             for (int j = 0; j <= MLO; ++j) acc[j] = 0.0;
@@ -606,9 +622,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
             };
             {   // half A: samples 32 l + ..., history = the MLO samples before (zero for lane 0)
                 const int g0 = 32 * lane;
-                float4 wv[8];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) wv[t] = *reinterpret_cast<const float4*>(win + g0 + 4 * t);
                 const int4 h7 = *reinterpret_cast<const int4*>(&smp[hist7]), h6 = *reinterpret_cast<const int4*>(&smp[hist6]);
                 const int4 h5 = *reinterpret_cast<const int4*>(&smp[hist5]);
                 const int hs[12] = {h7.w, h7.z, h7.y, h7.x, h6.w, h6.z, h6.y, h6.x, h5.w, h5.z, h5.y, h5.x};
@@ -617,17 +630,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
                     const float wh = (g0 - 1 - j >= 0) ? win[g0 - 1 - j] : 0.0f;
                     hist[j] = (double)hs[j] * (double)wh;
                 }
+                // window values four groups at a time (16 registers in flight, not 32: the kernel lives at 168)
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    lag_group(*reinterpret_cast<const int4*>(&smp[K ^ (4 * t)]), wv[t]);
-                    search_stage(t);
+                for (int tb = 0; tb < 8; tb += 4) {
+                    float4 wv[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) wv[t] = *reinterpret_cast<const float4*>(win + g0 + 4 * (tb + t));
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        lag_group(*reinterpret_cast<const int4*>(&smp[K ^ (4 * (tb + t))]), wv[t]);
+                        search_stage(tb + t);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             {   // half B
                 const int g0 = 2048 + 32 * lane;
-                float4 wv[8];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) wv[t] = *reinterpret_cast<const float4*>(win + g0 + 4 * t);
                 const int4 h7 = hist_b(Bv[7], *reinterpret_cast<const int4*>(&smp[tailA7]));
                 const int4 h6 = hist_b(Bv[6], *reinterpret_cast<const int4*>(&smp[tailA6]));
                 int4 h5 = make_int4(0, 0, 0, 0);
@@ -636,9 +654,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
 #pragma unroll
                 for (int j = 0; j < MLO; ++j) hist[j] = (double)hs[j] * (double)win[g0 - 1 - j];
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    lag_group(Bv[t], wv[t]);
-                    search_stage(8 + t);
+                for (int tb = 0; tb < 8; tb += 4) {
+                    float4 wv[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) wv[t] = *reinterpret_cast<const float4*>(win + g0 + 4 * (tb + t));
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        lag_group(Bv[tb + t], wv[t]);
+                        search_stage(8 + tb + t);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             FA_STAMP(4);
@@ -697,8 +722,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
                 for (int j = 0; j < MLO; ++j) qreg[j] = 0;
                 int ok = 0;
                 if (prec >= 2) ok = (quantize_coefs_t<MLO>(coef + (lo - 1) * MLO, lo, prec, qreg, &sh) == 0) ? 1 : 0;
+                // (wave-uniform values read from LDS: say so, and they live in scalar registers from here to the preamble)
+                ok = __builtin_amdgcn_readfirstlane(ok);
+                sh = __builtin_amdgcn_readfirstlane(sh);
+#pragma unroll
+                for (int j = 0; j < MLO; ++j) qreg[j] = __builtin_amdgcn_readfirstlane(qreg[j]);
                 FA_STAMP(6);
                 if (ok) {
+                    FA_IMAGE_ADDRS;
                     const double scale = bitsd((uint64_t)(1023 - sh) << 52);  // 2^-sh (exact pre-scaling, see K3)
                     double qd[MLO];
 #pragma unroll
@@ -802,6 +833,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
     FA_STAMP(8);
     // ---- materialise the winner's residual: LPC is in place; FIXED is recomputed from the samples -------
     auto reload_image = [&]() __attribute__((always_inline)) {
+        FA_IMAGE_ADDRS;
 #pragma unroll 1
         for (int half = 1; half >= 0; --half) {
 #pragma unroll
@@ -823,6 +855,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
             img_is_residual = false;
         }
         if (order > 0) {
+            FA_IMAGE_ADDRS;
             const int4 ha = *reinterpret_cast<const int4*>(&smp[hist7]);
             const int4 hb2 = hist_b(Bv[7], *reinterpret_cast<const int4*>(&smp[tailA7]));
             lds_fence();
@@ -863,6 +896,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
     const int plen = rice2 ? 5 : 4;
     uint32_t sub_bits;  // bits of the subframe
     if (type >= 2) {
+        FA_IMAGE_ADDRS;
         const int pA = (lane << porder) >> 7, pB = ((64 + lane) << porder) >> 7;
         const uint32_t kA = (uint32_t)__builtin_amdgcn_ds_bpermute(pA << 2, kbest);
         const uint32_t kB = (uint32_t)__builtin_amdgcn_ds_bpermute(pB << 2, kbest);
@@ -997,6 +1031,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
         crc_t = (uint32_t)crc_s[w >> 24] ^ (uint32_t)crc_s[256 + ((w >> 16) & 255u)] ^ (uint32_t)crc_s[512 + ((w >> 8) & 255u)] ^
                 (uint32_t)crc_s[768 + (w & 255u)];
     };
+    // Stores are destination-ALIGNED dwords (an unaligned dword store becomes partial-line writes: the first version
+    // wrote 2.6x the blob's bytes to the fabric, profiles/r02h_traffic.json).  The frame starts at dst, sh = dst & 3
+    // bytes past a dword boundary; aligned dword m (address dst - sh + 4 m) holds stream bytes [4 m - sh, 4 m - sh + 4),
+    // i.e. the last sh bytes of ring word m - 1 and the first 4 - sh of ring word m (big-endian words: one v_alignbit).
+    // Lane l takes word m - 1 from lane l - 1 (DPP), lane 0 from `carry`, the last word of the previous block.  Dwords
+    // that reach outside the frame's bytes [0, total_bytes) -- its first and last -- are written byte by byte: the
+    // neighbouring frames own the rest of them.
+    uint32_t carry = 0;
+    auto emit_word = [&](uint32_t m, uint32_t Q) __attribute__((always_inline)) {  // all lanes: ring word m = m0 + lane (0 beyond the frame)
+        const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u);
+        const uint32_t P = (uint32_t)dpp_wave_shr1((int)carry, (int)Q);
+        carry = (uint32_t)__builtin_amdgcn_readlane((int)Q, 63);
+        const uint32_t V = __builtin_amdgcn_alignbit(P, Q, 8u * sh);  // big-endian value of stream bytes [lo, lo + 4)
+        const int lo = (int)(4u * m) - (int)sh;
+        if (lo >= 0 && (uint32_t)lo + 4u <= total_bytes) {
+            *reinterpret_cast<uint32_t*>(dst + lo) = __builtin_bswap32(V);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int b = lo + i;
+                if (b >= 0 && (uint32_t)b < total_bytes) dst[b] = (uint8_t)(V >> (24 - 8 * i));
+            }
+        }
+    };
     auto flush_blocks = [&]() __attribute__((always_inline)) {
         const uint32_t done = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pos >> 11));
         blocks_flushed = (uint32_t)__builtin_amdgcn_readfirstlane((int)blocks_flushed);
@@ -1008,10 +1066,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
             ring[wi] = 0;
             if ((blocks_flushed & (uint32_t)(kFRingBlocks - 1)) == 0 && lane == 0) { wv |= ring[kFRingWords]; ring[kFRingWords] = 0; }
             crc_word(wv);
-            if (!dropped) {
-                const uint32_t be = __builtin_bswap32(wv);
-                __builtin_memcpy(dst + 256u * blocks_flushed + 4u * (uint32_t)lane, &be, 4);  // (dst has any byte alignment)
-            }
+            if (!dropped) emit_word(blocks_flushed * 64 + (uint32_t)lane, wv);
             blocks_flushed++;
         }
     };
@@ -1076,6 +1131,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
             flush_blocks();
         }
     } else if (type >= 2) {
+        FA_IMAGE_ADDRS;
         const uint32_t ps = (uint32_t)(bs >> porder);
         const int l2ps = 12 - porder;
         struct RowPrep {
@@ -1210,19 +1266,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
         if (lane == 0) put_bits(8u * L, crc, 16);
         lds_fence();
         if (!dropped) {
-            for (uint32_t w0 = blocks_flushed * 64; w0 < nwords; w0 += 64) {
+            // the remaining words, and one word of zeros after them: the aligned dword that holds the frame's last
+            // (up to 3) bytes starts in the last ring word
+            for (uint32_t w0 = blocks_flushed * 64; w0 <= nwords; w0 += 64) {
                 const uint32_t wl = w0 + lane;
+                uint32_t wv = 0;
                 if (wl < nwords) {
-                    uint32_t wv = ring[wl & kFRingMask];
+                    wv = ring[wl & kFRingMask];
                     if ((wl & kFRingMask) == 0) wv |= ring[kFRingWords];
-                    const uint32_t be = __builtin_bswap32(wv);
-                    const uint32_t o = 4u * wl;
-                    if (o + 4u <= total_bytes) {
-                        __builtin_memcpy(dst + o, &be, 4);
-                    } else {  // the frame ends inside this word: byte stores, the next frame owns what follows
-                        for (uint32_t b = o; b < total_bytes; ++b) dst[b] = (uint8_t)(be >> (8u * (b - o)));
-                    }
                 }
+                emit_word(wl, wv);
             }
         }
     }
@@ -1272,5 +1325,48 @@ __global__ __launch_bounds__(256) void fused_finish_kernel(uint8_t* __restrict__
         p[17] = (uint8_t)bsz;
     }
 }
+
+#endif  // the kernels
+
+// host-side launchers (defined in the unit that holds the kernels: csrc/fused_unit.hip in the shipped build, compiled
+// with the default scheduling strategy -- max-ILP, which the slot encoder and the decoder like, costs this kernel
+// registers it does not have)
+void launch_fused_encode(hipStream_t st, const FusedArgs& a, bool f32)
+#if defined(FA_UNIT_FUSED) || !defined(FA_SPLIT_UNITS)
+{
+    const dim3 grid((unsigned)((a.total_frames + kFWaves - 1) / kFWaves) + 1u);  // + the scanner's workgroup
+    const dim3 block(64 * kFWaves);
+#ifdef FA_DEV_MINIMAL  // diagnostic builds: the level 3-5 kernels only
+    if (f32) hipLaunchKernelGGL((encode_fused_kernel<8, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((encode_fused_kernel<8, false>), grid, block, 0, st, a);
+#else
+    if (f32) {
+        switch (a.max_lpc_order) {
+            case 6: hipLaunchKernelGGL((encode_fused_kernel<6, true>), grid, block, 0, st, a); break;
+            case 8: hipLaunchKernelGGL((encode_fused_kernel<8, true>), grid, block, 0, st, a); break;
+            default: hipLaunchKernelGGL((encode_fused_kernel<12, true>), grid, block, 0, st, a); break;
+        }
+    } else {
+        switch (a.max_lpc_order) {
+            case 6: hipLaunchKernelGGL((encode_fused_kernel<6, false>), grid, block, 0, st, a); break;
+            case 8: hipLaunchKernelGGL((encode_fused_kernel<8, false>), grid, block, 0, st, a); break;
+            default: hipLaunchKernelGGL((encode_fused_kernel<12, false>), grid, block, 0, st, a); break;
+        }
+    }
+#endif
+}
+#else
+;
+#endif
+void launch_fused_finish(hipStream_t st, uint8_t* out, const int64_t* frame_abs, const uint32_t* frame_bytes, int64_t n_stream,
+                         int64_t nframes, int64_t stream_size, int64_t hb, int64_t* starts, int64_t* nbytes, int64_t* total)
+#if defined(FA_UNIT_FUSED) || !defined(FA_SPLIT_UNITS)
+{
+    hipLaunchKernelGGL(fused_finish_kernel, dim3((unsigned)n_stream), dim3(256), 0, st, out, frame_abs, frame_bytes, n_stream, nframes,
+                       stream_size, (int32_t)kMaxBlock, (int32_t)kMaxBlock, 1, hb, starts, nbytes, total);
+}
+#else
+;
+#endif
 
 }  // namespace fa

@@ -529,7 +529,7 @@ template <int MLO, int NCH = 1>
 #ifndef FA_K3_WAVES_ATTR
 #define FA_K3_WAVES_ATTR
 #endif
-__global__ __launch_bounds__(64) FA_K3_WAVES_ATTR void encode_frames_kernel(EncodeArgs a) {
+FA_GLOBAL __global__ __launch_bounds__(64) FA_K3_WAVES_ATTR void encode_frames_kernel(EncodeArgs a) {
     constexpr int kScrWords = (NCH == 2) ? 256 : 0;  // analysis scratch: the ring holds live bits while channel 1 is analysed
 #ifdef FA_LDS_PAD
     __shared__ __attribute__((aligned(16))) int32_t lds[kLdsWords + kScrWords + FA_LDS_PAD];  // occupancy experiment
@@ -1413,7 +1413,7 @@ __global__ __launch_bounds__(64) FA_K3_WAVES_ATTR void encode_frames_kernel(Enco
 // K4: sizes -> offsets
 // ------------------------------------------------------------------------------------------
 // one 256-thread block per stream: exclusive scan of its frame sizes
-__global__ __launch_bounds__(256) void stream_scan_kernel(const uint32_t* __restrict__ frame_bytes, int64_t nframes,
+FA_GLOBAL __global__ __launch_bounds__(256) void stream_scan_kernel(const uint32_t* __restrict__ frame_bytes, int64_t nframes,
                                                           int64_t* __restrict__ frame_off, int64_t* __restrict__ stream_nbytes) {
     __shared__ uint64_t sh[256];
     __shared__ uint64_t carry;
@@ -1442,7 +1442,7 @@ __global__ __launch_bounds__(256) void stream_scan_kernel(const uint32_t* __rest
 }
 
 // single 1024-thread block: exclusive scan of stream sizes -> starts, total
-__global__ __launch_bounds__(1024) void starts_scan_kernel(const int64_t* __restrict__ stream_nbytes, int64_t n_stream,
+FA_GLOBAL __global__ __launch_bounds__(1024) void starts_scan_kernel(const int64_t* __restrict__ stream_nbytes, int64_t n_stream,
                                                            int64_t* __restrict__ starts, int64_t* __restrict__ total) {
     __shared__ uint64_t sh[1024];
     __shared__ uint64_t carry;
@@ -1479,7 +1479,7 @@ __global__ __launch_bounds__(1024) void starts_scan_kernel(const int64_t* __rest
 // ------------------------------------------------------------------------------------------
 // K5a: stream headers.  One 256-thread block per stream.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void write_headers_kernel(uint8_t* __restrict__ out, const int64_t* __restrict__ starts,
+FA_GLOBAL __global__ __launch_bounds__(256) void write_headers_kernel(uint8_t* __restrict__ out, const int64_t* __restrict__ starts,
                                                             const int64_t* __restrict__ frame_off, int64_t nframes,
                                                             int64_t stream_size, int32_t B, int32_t tail_bs, int32_t nch) {
     const int64_t s = blockIdx.x;
@@ -1540,7 +1540,7 @@ __device__ __forceinline__ uint16_t crc_mulmod(uint16_t a, uint16_t b) {
 }
 
 // (eight waves per SIMD: this kernel lives on memory-level parallelism, whatever the scheduling strategy of the build)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void compact_frames_kernel(const uint8_t* __restrict__ slots,
+FA_GLOBAL __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void compact_frames_kernel(const uint8_t* __restrict__ slots,
                                                              const uint32_t* __restrict__ frame_bytes,
                                                              const int64_t* __restrict__ frame_off,
                                                              const int64_t* __restrict__ starts, int64_t nframes,

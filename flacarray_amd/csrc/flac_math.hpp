@@ -14,6 +14,14 @@
 #define FA_HD inline
 #endif
 
+// Non-template kernels defined in headers that more than one translation unit includes get internal linkage in the
+// secondary units (the unit that launches them keeps the external definition).
+#if defined(FA_UNIT_FUSED)
+#define FA_GLOBAL static
+#else
+#define FA_GLOBAL
+#endif
+
 namespace fa {
 
 constexpr int kMaxBlock = 4096;        // largest frame the kernels stage in LDS

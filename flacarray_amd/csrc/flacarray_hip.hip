@@ -24,6 +24,7 @@
 #include "encode_kernels.hpp"
 #include "encode_fused.hpp"
 #include "quantize_kernels.hpp"
+#include "verify_kernels.hpp"
 
 namespace {
 
@@ -67,6 +68,7 @@ struct DeviceState {
 std::mutex g_mu;
 std::map<int, std::unique_ptr<DeviceState>> g_dev;
 std::atomic<bool> g_prof{false};
+std::atomic<bool> g_verify{false};  // fa_set_decode_verify: re-compute every decoded frame's CRC-16
 
 DeviceState* dev_state() {
     int d = 0;
@@ -309,9 +311,17 @@ void make_fused_plan(int64_t n_stream, int64_t stream_size, uint32_t level, Fuse
     pl->capacity = pl->F * (int64_t)kSlotBytes + n_stream * pl->hb;
 }
 
-template <int MLO, bool F32IN>
-void launch_fused(const FusedArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL((encode_fused_kernel<MLO, F32IN>), dim3((unsigned)((a.total_frames + kFWaves - 1) / kFWaves) + 1u), dim3(64 * kFWaves), 0, st, a);  // + the scanner's workgroup
+
+// optional CRC-16 check of every frame the decode just read (verify_kernels.hpp); h_err receives the refreshed flags
+int run_verify(const DecodeArgs& a, int* d_err, int* h_err, hipStream_t st) {
+    if (!g_verify) return FA_ERROR_NONE;
+    const uint16_t* tab = nullptr;
+    int rc = get_crc_tab_fused(&tab);
+    if (rc) return rc;
+    hipLaunchKernelGGL(verify_crc16_kernel, dim3((unsigned)((a.n_tasks + 3) / 4)), dim3(256), 0, st, a, tab);
+    FA_HIP_TRY(hipMemcpyAsync(h_err, d_err, 16, hipMemcpyDeviceToHost, st));
+    FA_HIP_TRY(hipStreamSynchronize(st));
+    return FA_ERROR_NONE;
 }
 
 int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int64_t* d_starts, const int64_t* d_nbytes,
@@ -452,6 +462,7 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
         FA_HIP_TRY(hipMemcpyAsync(h_err, d_err, 16, hipMemcpyDeviceToHost, st));
         FA_HIP_TRY(hipStreamSynchronize(st));
         FA_HIP_TRY(hipGetLastError());
+        if ((rc = run_verify(a, d_err, h_err, st))) return rc;
         return h_err[0];
     }
 #endif
@@ -463,6 +474,7 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
     prof_end(4, st);
     FA_HIP_TRY(hipMemcpyAsync(h_err, d_err, 16, hipMemcpyDeviceToHost, st));
     FA_HIP_TRY(hipStreamSynchronize(st));
+    if ((rc = run_verify(a, d_err, h_err, st))) return rc;
     return h_err[0] | (h_err[1] ? FA_ERROR_DECODE_PROCESS : 0);
 #else
     if (f32) hipLaunchKernelGGL((decode_frames_kernel<8, -1, true, 1>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
@@ -484,6 +496,7 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
         FA_HIP_TRY(hipStreamSynchronize(st));
     }
     FA_HIP_TRY(hipGetLastError());
+    if ((rc = run_verify(a, d_err, h_err, st))) return rc;
     return h_err[0];
 #endif
 }
@@ -506,6 +519,11 @@ int validate_range(int64_t stream_size, int64_t first_sample, int64_t last_sampl
 extern "C" {
 
 const char* fa_version(void) { return "flacarray_hip 0.1.0 (gfx950)"; }
+
+int fa_set_decode_verify(int on) {
+    const bool was = g_verify.exchange(on != 0);
+    return was ? 1 : 0;
+}
 
 void fa_profile_enable(int on) { g_prof = (on != 0); }  // process-wide switch; the events are per device
 
@@ -802,28 +820,10 @@ static int fused_encode_run(const void* d_data, bool f32, const float* d_quanta,
     }
 #endif
     prof_begin(0, st);
-#ifdef FA_DEV_MINIMAL
-    if (f32) launch_fused<8, true>(a, st);
-    else launch_fused<8, false>(a, st);
-#else
-    if (f32) {
-        switch (a.max_lpc_order) {
-            case 6: launch_fused<6, true>(a, st); break;
-            case 8: launch_fused<8, true>(a, st); break;
-            default: launch_fused<12, true>(a, st); break;
-        }
-    } else {
-        switch (a.max_lpc_order) {
-            case 6: launch_fused<6, false>(a, st); break;
-            case 8: launch_fused<8, false>(a, st); break;
-            default: launch_fused<12, false>(a, st); break;
-        }
-    }
-#endif
+    launch_fused_encode(st, a, f32);
     prof_end(0, st);
     int64_t* d_total = reinterpret_cast<int64_t*>(ws + pl.off_total);
-    hipLaunchKernelGGL(fused_finish_kernel, dim3((unsigned)n_stream), dim3(256), 0, st, d_bytes, a.frame_abs, a.frame_bytes, n_stream,
-                       pl.nf, stream_size, (int32_t)kMaxBlock, (int32_t)kMaxBlock, 1, pl.hb, d_starts, d_nbytes, d_total);
+    launch_fused_finish(st, d_bytes, a.frame_abs, a.frame_bytes, n_stream, pl.nf, stream_size, pl.hb, d_starts, d_nbytes, d_total);
     prof_end(3, st);
     int h_err = 0, h_nan = 0;
     FA_HIP_TRY(hipMemcpyAsync(&h_err, a.err, 4, hipMemcpyDeviceToHost, st));

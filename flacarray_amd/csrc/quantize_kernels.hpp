@@ -26,7 +26,7 @@ __device__ __forceinline__ int64_t x86_cvtt_i64(double v) {
 
 // One 1024-thread block per stream: pass 1 min/max (HBM read), pass 2 convert (re-read is
 // served by L2 / Infinity Cache for streams up to tens of MB).
-__global__ __launch_bounds__(1024) void float32_to_int32_kernel(const float* __restrict__ input, int64_t stream_size,
+FA_GLOBAL __global__ __launch_bounds__(1024) void float32_to_int32_kernel(const float* __restrict__ input, int64_t stream_size,
                                                                 const float* __restrict__ quanta, int32_t* __restrict__ output,
                                                                 float* __restrict__ offsets, float* __restrict__ gains,
                                                                 int* __restrict__ flags) {
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(1024) void float32_to_int32_kernel(const float* __r
 // K1b: one thread per stream folds the chunk results into offset and gain, with exactly the arithmetic of K1 / utils.c:194-230.
 // The samples are then quantised where the encoder loads them (quantise_f32): 4 B per sample read once more, nothing written.
 constexpr int kRangeChunk = 65536;
-__global__ __launch_bounds__(256) void float32_range_kernel(const float* __restrict__ input, int64_t stream_size, int64_t chunks_per_stream,
+FA_GLOBAL __global__ __launch_bounds__(256) void float32_range_kernel(const float* __restrict__ input, int64_t stream_size, int64_t chunks_per_stream,
                                                             float* __restrict__ part_min, float* __restrict__ part_max,
                                                             int* __restrict__ flags) {
     __shared__ float s_min[4], s_max[4];
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void float32_range_kernel(const float* __restr
     }
 }
 
-__global__ __launch_bounds__(256) void float32_params_kernel(const float* __restrict__ part_min, const float* __restrict__ part_max,
+FA_GLOBAL __global__ __launch_bounds__(256) void float32_params_kernel(const float* __restrict__ part_min, const float* __restrict__ part_max,
                                                              int64_t n_stream, int64_t chunks_per_stream, const float* __restrict__ quanta,
                                                              float* __restrict__ offsets, float* __restrict__ gains) {
     const int64_t is = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -197,7 +197,7 @@ __device__ __forceinline__ int32_t quantise_f32(float x, float off, float gain) 
 
 // grid = (chunks per stream, n_stream folded into x); each block converts up to 16384 samples
 constexpr int kDequantChunk = 16384;
-__global__ __launch_bounds__(256) void int32_to_float32_kernel(const int32_t* __restrict__ input, int64_t stream_size,
+FA_GLOBAL __global__ __launch_bounds__(256) void int32_to_float32_kernel(const int32_t* __restrict__ input, int64_t stream_size,
                                                                int64_t chunks_per_stream, const float* __restrict__ offsets,
                                                                const float* __restrict__ gains, float* __restrict__ output) {
     const int64_t is = blockIdx.x / chunks_per_stream;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void int32_to_float32_kernel(const int32_t* __
 }
 
 // ---- float64 <-> int64 (utils.c:245-348): every operation is a double operation ------------------
-__global__ __launch_bounds__(1024) void float64_to_int64_kernel(const double* __restrict__ input, int64_t stream_size,
+FA_GLOBAL __global__ __launch_bounds__(1024) void float64_to_int64_kernel(const double* __restrict__ input, int64_t stream_size,
                                                                 const double* __restrict__ quanta, int64_t* __restrict__ output,
                                                                 double* __restrict__ offsets, double* __restrict__ gains,
                                                                 int* __restrict__ flags) {
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(1024) void float64_to_int64_kernel(const double* __
     }
 }
 
-__global__ __launch_bounds__(256) void int64_to_float64_kernel(const int64_t* __restrict__ input, int64_t stream_size,
+FA_GLOBAL __global__ __launch_bounds__(256) void int64_to_float64_kernel(const int64_t* __restrict__ input, int64_t stream_size,
                                                                int64_t chunks_per_stream, const double* __restrict__ offsets,
                                                                const double* __restrict__ gains, double* __restrict__ output) {
     const int64_t is = blockIdx.x / chunks_per_stream;

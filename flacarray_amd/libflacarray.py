@@ -320,6 +320,14 @@ def encode_flac_device(data, level=5, workspace=None, return_info=False, compact
     return out
 
 
+def set_decode_verify(on):
+    """Process-wide switch of the decoder's integrity pass: when on, every decode call re-computes the CRC-16 of each
+    frame it read and raises ("Decoding failed, return code = 16384", ERROR_DECODE_PROCESS) on a mismatch -- the
+    condition libFLAC reports through the error callback the reference prints (decompress.c:104-121).  Returns the
+    previous setting.  Off by default: the pass re-reads the compressed bytes."""
+    return bool(_lib.lib().fa_set_decode_verify(1 if on else 0))
+
+
 def encode_flac_device_f32(data, quanta=None, level=5, workspace=None, compact=False):
     """Quantise and encode a C-contiguous float32 CUDA tensor [..., stream_size] held in HBM: the device-resident
     analogue of array_compress on float32 input (compress.py:50-84 -> float_to_int + encode_flac).

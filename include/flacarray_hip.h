@@ -156,6 +156,12 @@ int fa_decode_i64_device(const unsigned char* d_bytes, int64_t n_bytes, const in
                          int64_t last_sample, int64_t* d_out_i64, double* d_out_f64, const double* d_offsets,
                          const double* d_gains, void* stream);
 
+/* Integrity check of the decoder (process-wide switch, returns the previous setting; default off).  When on, every
+ * decode call re-computes the CRC-16 of each frame it read and reports a mismatch as FA_ERROR_DECODE_PROCESS -- what
+ * libFLAC reports through the error callback the reference prints (decompress.c:104-121).  The header CRC-8 of every
+ * frame is always checked. */
+int fa_set_decode_verify(int on);
+
 /* Batched random access: slice i is samples [first[i], first[i]+count[i]) of stream
  * slice_stream[i]; its samples are written at element offset out_offset[i] of the output.
  * The four slice arrays are HOST arrays of length n_slices.  The reference needs one

@@ -216,6 +216,44 @@ def test_corrupt_stream_reports_error(fa, oracle):
         fa.decode_flac(bad, st, nb, 9000)
 
 
+def test_frame_crc16_verification(fa, oracle):
+    """A flipped sample bit passes every header check: without the integrity pass the decoder returns (wrong)
+    samples with code 0, as DESIGN.md says; with fa.set_decode_verify(True) it is ERROR_DECODE_PROCESS.  Intact
+    streams -- own, oracle-written and without a SEEKTABLE -- pass the check, whole and in slices."""
+    import torch
+
+    from tests.conftest import strip_seektable
+
+    x = full_range_i32((3, 20000), seed=41)  # VERBATIM frames: a flipped sample bit cannot desynchronise the parse
+    blob, st, nb = oracle.encode_i32(x, 5)
+    nf = 5
+    hb = 4 + 4 + 34 + 4 + 18 * nf
+    bad = blob.copy()
+    bad[int(st[1]) + hb + 3000] ^= 0x04  # inside frame 0 of stream 1, far from any header
+    d = lambda b: (torch.from_numpy(b).cuda(), torch.from_numpy(st).cuda(), torch.from_numpy(nb).cuda())  # noqa: E731
+    assert fa.set_decode_verify(False) is False
+    y = fa.decode_flac_device(*d(bad), 20000).cpu().numpy()
+    assert np.array_equal(y[0], x[0]) and np.array_equal(y[2], x[2]) and not np.array_equal(y[1], x[1])
+    try:
+        assert fa.set_decode_verify(True) is False
+        with pytest.raises(RuntimeError, match="Decoding failed"):
+            fa.decode_flac_device(*d(bad), 20000)
+        with pytest.raises(RuntimeError, match="Decoding failed"):
+            fa.decode_flac_device(*d(bad), 20000, 100, 200)  # the damaged frame is the one the slice reads
+        assert np.array_equal(fa.decode_flac_device(*d(bad), 20000, 9000, 9500).cpu().numpy(), x[:, 9000:9500])  # others are untouched
+        assert np.array_equal(fa.decode_flac_device(*d(blob), 20000).cpu().numpy(), x)
+        b2, s2, n2 = strip_seektable(blob, st, nb)
+        assert np.array_equal(fa.decode_flac_device(torch.from_numpy(b2).cuda(), torch.from_numpy(s2).cuda(), torch.from_numpy(n2).cuda(), 20000).cpu().numpy(), x)
+        xg = sinusoid_noise_i32(4, 8192, seed=42)
+        cg, sg, ng = fa.encode_flac_device(torch.from_numpy(xg).cuda())  # single-pass encoder's own CRCs
+        assert np.array_equal(fa.decode_flac_device(cg, sg, ng, 8192).cpu().numpy(), xg)
+        assert np.array_equal(fa.decode_flac(bad, st, nb, 20000, first_sample=9000, last_sample=9500), x[:, 9000:9500])  # host ABI
+        with pytest.raises(RuntimeError, match="Decoding failed"):
+            fa.decode_flac(bad, st, nb, 20000)
+    finally:
+        assert fa.set_decode_verify(False) is True
+
+
 def test_float_array_path(fa, oracle):
     """array_compress / array_decompress on float32 (quanta scalar, per-stream array, precision)."""
     x = sinusoid_noise_f32(6, 30000, seed=12).reshape(2, 3, 30000)

@@ -13,7 +13,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 src = os.path.join(root, "gpurun_out")
 dst = os.path.join(root, "profiles")
-KERN = ("encode_frames_kernel", "compact_frames_kernel", "decode_frames_kernel")
+KERN = ("encode_fused_kernel", "encode_frames_kernel", "compact_frames_kernel", "decode_frames_kernel", "float32_range_kernel")
 
 
 def one(pattern):
@@ -61,7 +61,7 @@ out = {
     "instruction_mix": {},
 }
 for k in F:
-    corr = 2.0 if "encode_frames" in k else 1.0
+    corr = 2.0 if ("encode_frames" in k or "encode_fused" in k or "float32_range" in k) else 1.0
     f, w = F[k]["FETCH_SIZE"], W.get(k, {}).get("WRITE_SIZE", 0.0)
     out["kernels"][k] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "fetch_correction": corr, "hbm_bytes": (f * corr + w) * 1024.0}
 for k, c in I.items():
