@@ -25,7 +25,7 @@
 // 256 entries per step, and stores the absolute byte offset of every frame it passes into off_pub[g] (never zero).
 // A frame polls only its own off_pub word: no two frames wait on the same address, and nobody polls the words the
 // publishers write (a first version in which every waiting wave polled shared per-group counters ran 2-3x slower:
-// thousands of pollers on the few cache lines the publishers needed, profiles/r02_single_pass_experiments.md).
+// thousands of pollers on the few cache lines the publishers needed, profiles/r02_single_pass/README.md).
 #pragma once
 #include "encode_kernels.hpp"
 #include "quantize_kernels.hpp"
@@ -91,6 +91,9 @@ __device__ __forceinline__ int lane_id_opaque() {  // the lane number, recompute
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
     return l;
 }
+// zig-zag fold of a residual (RFC 9639 9.2.7.3).  The residual passes store the folded value: the exact-size pass and
+// the row writer both start from it, the Rice parameter search needs only the magnitude sums taken before the fold.
+__device__ __forceinline__ int rice_fold(int r) { return (int)(((uint32_t)r << 1) ^ (uint32_t)(r >> 31)); }
 __device__ __forceinline__ int dpp_wave_shr1(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x138, 0xF, 0xF, false); }
 
 __device__ __forceinline__ uint16_t crc16_mulmod(uint16_t a, uint16_t b) {  // a * b mod x^16 + x^15 + x^2 + 1
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
     orv = wave_or_u32(orv);
     const int wasted = orv ? (__ffs((int)orv) - 1) : 0;
     const int bps = 32 - wasted;
-    if (wasted) {
+    if (__builtin_expect(wasted != 0, 0)) {
         FA_IMAGE_ADDRS;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
     int type = 1;  // 0 const, 1 verbatim, 2 fixed, 3 lpc
     int order = 0, porder = 0, shift = 0, precision = 0;
     int kbest = 0;
-    bool img_is_residual = false;
+    bool img_is_residual = false;  // the image holds (folded) residuals, warm-up samples excepted
     int fo = -1;
     int32_t qkeep[MLO];
 #pragma unroll
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
         return h;
     };
 
-    if (is_const) {
+    if (__builtin_expect(is_const, 0)) {
         type = 0;
     } else {
         uint64_t best_bits = verbatim_bits;
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
         // per-half sums of the winner are needed for the partition search: keep both halves of every order
         uint64_t hA0 = 0, hA1 = 0, hA2 = 0, hA3 = 0, hA4 = 0;
         double dA0 = 0.0, dA1 = 0.0, dA2 = 0.0, dA3 = 0.0, dA4 = 0.0;
-        if (narrow) {
+        if (__builtin_expect(narrow, 1)) {
             FA_IMAGE_ADDRS;
             const uint32_t BIAS = 0x80000000u;
             uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
                 kbest = k_fix;
             }
         };
-        if (fo >= 0 && !fuse_search) {
+        if (__builtin_expect(fo >= 0 && !fuse_search, 0)) {
             uint64_t rb;
             if (pmax_fix <= 5 && small_fix) {
                 SplitRiceSearch fs;
@@ -591,7 +594,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
         FA_STAMP(2);
         // ---- P3: LPC analysis ---------------------------------------------------------------------------
         int mlo = a.max_lpc_order;
-        if (mlo > 0) {
+        if (__builtin_expect(mlo > 0, 1)) {
             FA_IMAGE_ADDRS;
             double acc[MLO + 1];
 #pragma unroll
@@ -678,7 +681,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
             for (int j = 0; j <= MLO; ++j) autoc[j] = wave_sum_butterfly(acc[j]);
 
             FA_STAMP(5);
-            if (autoc[0] != 0.0) {
+            if (__builtin_expect(autoc[0] != 0.0, 1)) {
                 float* coef = reinterpret_cast<float*>(scr);         // MLO*MLO floats
                 double* err = reinterpret_cast<double*>(scr + 160);  // MLO doubles
                 int* meta = reinterpret_cast<int*>(scr + 220);       // usable order
@@ -728,7 +731,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
 #pragma unroll
                 for (int j = 0; j < MLO; ++j) qreg[j] = __builtin_amdgcn_readfirstlane(qreg[j]);
                 FA_STAMP(6);
-                if (ok) {
+                if (__builtin_expect(ok != 0, 1)) {
                     FA_IMAGE_ADDRS;
                     const double scale = bitsd((uint64_t)(1023 - sh) << 52);  // 2^-sh (exact pre-scaling, see K3)
                     double qd[MLO];
@@ -762,12 +765,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
                                 const double ar = v ? fa_fabs(r) : 0.0;
                                 tl += ar;
                                 mxr = __builtin_fmax(mxr, ar);
-                                rs[e] = v ? (int)r : xs[e];
+                                rs[e] = v ? rice_fold((int)r) : xs[e];
                             } else {
                                 const double ar = fa_fabs(r);
                                 tl += ar;
                                 mxr = __builtin_fmax(mxr, ar);
-                                rs[e] = (int)r;
+                                rs[e] = rice_fold((int)r);
                             }
 #pragma unroll
                             for (int j = MLO - 1; j > 0; --j) hx[j] = hx[j - 1];
@@ -849,12 +852,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
         }
         lds_fence();
     };
-    if (type == 2) {
+    if (__builtin_expect(type == 2, 0)) {
         if (img_is_residual) {
             reload_image();
             img_is_residual = false;
         }
-        if (order > 0) {
+        {   // (order 0: the residual is the sample itself, folded like any other)
             FA_IMAGE_ADDRS;
             const int4 ha = *reinterpret_cast<const int4*>(&smp[hist7]);
             const int4 hb2 = hist_b(Bv[7], *reinterpret_cast<const int4*>(&smp[tailA7]));
@@ -867,11 +870,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
                 for (int e = 0; e < 4; ++e) {
                     const int64_t x0 = xs[e];
                     int64_t r;
-                    if (order == 1) r = x0 - x1;
+                    if (order == 0) r = x0;
+                    else if (order == 1) r = x0 - x1;
                     else if (order == 2) r = x0 - 2 * x1 + x2;
                     else if (order == 3) r = x0 - 3 * x1 + 3 * x2 - x3;
                     else r = x0 - 4 * x1 + 6 * x2 - 4 * x3 + x4;
-                    rs[e] = (gi0 + e >= order) ? (int)r : xs[e];
+                    rs[e] = (gi0 + e >= order) ? rice_fold((int)r) : xs[e];
                     x4 = x3; x3 = x2; x2 = x1; x1 = x0;
                 }
                 return make_int4(rs[0], rs[1], rs[2], rs[3]);
@@ -907,7 +911,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
             const int rs[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const uint32_t u = ((uint32_t)rs[e] << 1) ^ (uint32_t)(rs[e] >> 31);
+                const uint32_t u = (uint32_t)rs[e];  // (folded where the residual was computed)
                 uint32_t q = min(u >> k, 16384u);  // (a code this long overflows its row anyway: the sums stay small)
                 if constexpr (MASK) q = (gi0 + e >= order) ? (q + k + 1u) : 0u;
                 acc += q;
@@ -1114,7 +1118,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
     FA_STAMP(10);
 
     // ---- rows -------------------------------------------------------------------------------------------
-    if (type == 1) {
+    if (__builtin_expect(type == 1, 0)) {
         // VERBATIM: rows straight from global memory (the image may hold a residual)
         const uint32_t mask = (bps == 32) ? 0xffffffffu : ((1u << bps) - 1u);
 #pragma unroll 1
@@ -1157,7 +1161,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
             uint32_t len = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const uint32_t u = ((uint32_t)rs[e] << 1) ^ (uint32_t)(rs[e] >> 31);
+                const uint32_t u = (uint32_t)rs[e];  // (folded where the residual was computed)
                 uint32_t q = u >> R.k;
                 if constexpr (FIRST) {
                     const uint32_t gi = gb + (uint32_t)e;

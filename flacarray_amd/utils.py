@@ -45,77 +45,79 @@ def compressed_dtype(n_channel, offsets, gains):
     return np.dtype(np.int32) if is_int else np.dtype(np.float32)
 
 
-def float_to_int(data, quanta=None, precision=None):
-    """Convert float32 data to int32 with a per-stream offset and gain.
+# binding-layer entry point per dtype, by NAME (looked up when called: the CPU tests swap these module attributes)
+_FLOAT_TO_INT = {np.dtype(np.float32): "wrap_float32_to_int32", np.dtype(np.float64): "wrap_float64_to_int64"}
+_INT_TO_FLOAT = {np.dtype(np.int32): ("wrap_int32_to_float32", np.float32), np.dtype(np.int64): ("wrap_int64_to_float64", np.float64)}
 
-    Returns (integer data, offset array, gain array); single-stream input gives 1-element
-    offset/gain arrays (utils.py:325-342).
-    """
+
+def _streams_of(arr):
+    """(leading shape, number of streams, stream length) of an array whose last axis is the stream axis."""
+    lead = arr.shape[:-1]
+    return lead, (int(np.prod(lead)) if lead else 1), arr.shape[-1]
+
+
+def _per_stream(values, lead, what):
+    """`values` as an array shaped like the leading axes: a scalar is broadcast, an array must already match
+    (the reference's message for a mismatch, utils.py:287-290 / :305-308)."""
+    if not hasattr(values, "__len__"):
+        return None, values
+    arr = np.asarray(values)
+    if arr.shape != lead:
+        msg = f"{what} array ({arr}) has shape that does not "
+        msg += f"match leading shape of data ({arr.shape} != {lead})"
+        raise RuntimeError(msg)
+    return arr, None
+
+
+def _quanta_for(data, lead, quanta, precision):
+    """The quanta handed to the C layer: a zero-length array means "derive them from the data range"
+    (libflacarray.pyx:142-144); `precision` p stands for quanta = rms / 10^p per stream (utils.py:284-296)."""
+    if precision is not None:
+        rms = np.std(data, axis=-1, keepdims=True).reshape(lead)
+        p_arr, p_scalar = _per_stream(precision, lead, "precision")
+        quanta = rms / 10 ** (p_arr.reshape(lead) if p_arr is not None else p_scalar)
+    if quanta is None:
+        return np.zeros(0, dtype=data.dtype)
+    q_arr, q_scalar = _per_stream(quanta, lead, "quanta")
+    if q_arr is None:
+        q_arr = np.full(lead, q_scalar, dtype=data.dtype)
+    return q_arr.reshape(-1).astype(data.dtype)
+
+
+def float_to_int(data, quanta=None, precision=None):
+    """Quantise float32 / float64 data to int32 / int64 with one offset and gain per stream (utils.py:246-342).
+
+    Exactly one of `quanta` (scalar or one value per stream) and `precision` (decimal digits kept relative to each
+    stream's rms) may be given; neither means quanta from each stream's range.  Returns (integers shaped like
+    `data`, offsets, gains); offsets / gains have the leading shape, one element for a single stream."""
     if np.any(np.isnan(data)):
         raise RuntimeError("Cannot convert data with NaNs to integers")
     if quanta is not None and precision is not None:
         raise RuntimeError("Cannot specify both quanta and precision")
-    if data.dtype != np.dtype(np.float32) and data.dtype != np.dtype(np.float64):
+    convert = _FLOAT_TO_INT.get(data.dtype)
+    if convert is None:
         raise ValueError("Only float32 and float64 data are supported")
-    is_f64 = data.dtype == np.dtype(np.float64)
-
-    leading_shape = data.shape[:-1]
-    n_stream = 1 if len(leading_shape) == 0 else int(np.prod(leading_shape))
-    stream_size = data.shape[-1]
-
-    if precision is not None:
-        rms = np.std(data, axis=-1, keepdims=True)
-        if hasattr(precision, "__len__"):
-            precision = np.asarray(precision)
-            if precision.shape != leading_shape:
-                msg = f"precision array ({precision}) has shape that does not "
-                msg += f"match leading shape of data ({precision.shape} != {leading_shape})"
-                raise RuntimeError(msg)
-            quanta = rms.reshape(leading_shape) / 10 ** precision.reshape(leading_shape)
-        else:
-            quanta = rms.reshape(leading_shape) / 10**precision
-
-    if quanta is None:
-        quanta = np.zeros(0, dtype=data.dtype)  # "compute it from the data range"
-    elif hasattr(quanta, "__len__"):
-        quanta = np.asarray(quanta)
-        if quanta.shape != leading_shape:
-            msg = f"quanta array ({quanta}) has shape that does not "
-            msg += f"match leading shape of data ({quanta.shape} != {leading_shape})"
-            raise RuntimeError(msg)
-    else:
-        quanta = quanta * np.ones(leading_shape, dtype=data.dtype)
-
-    output, offsets, gains = (wrap_float64_to_int64 if is_f64 else wrap_float32_to_int32)(
-        np.ascontiguousarray(data).reshape((-1,)), n_stream, stream_size, np.asarray(quanta).reshape((-1,)).astype(data.dtype)
-    )
-    if len(leading_shape) == 0:
-        return (output.reshape(data.shape), offsets.reshape((-1,)), gains.reshape((-1,)))
-    return (output.reshape(data.shape), offsets.reshape(leading_shape), gains.reshape(leading_shape))
+    lead, n_stream, stream_size = _streams_of(data)
+    ints, offsets, gains = globals()[convert](np.ascontiguousarray(data).reshape(-1), n_stream, stream_size, _quanta_for(data, lead, quanta, precision))
+    aux_shape = lead if lead else (-1,)
+    return (ints.reshape(data.shape), offsets.reshape(aux_shape), gains.reshape(aux_shape))
 
 
 def int_to_float(idata, offset, gain):
-    """Restore float32 data from int32 (utils.py:346-408)."""
-    if idata.dtype != np.dtype(np.int32) and idata.dtype != np.dtype(np.int64):
+    """Restore float32 / float64 data from int32 / int64 with the per-stream offset and gain (utils.py:346-408)."""
+    pair = _INT_TO_FLOAT.get(idata.dtype)
+    if pair is None:
         raise ValueError("Input data should be int32 or int64")
-    is_i64 = idata.dtype == np.dtype(np.int64)
-    ftype = np.float64 if is_i64 else np.float32
-    leading_shape = idata.shape[:-1]
-    if len(leading_shape) == 0 or (len(leading_shape) == 1 and leading_shape[0] == 1):
-        n_stream = 1
-        offset = ensure_one_element(offset, ftype)
-        gain = ensure_one_element(gain, ftype)
+    restore, ftype = pair
+    lead, n_stream, stream_size = _streams_of(idata)
+    if n_stream == 1 and len(lead) <= 1:
+        offset, gain = ensure_one_element(offset, ftype), ensure_one_element(gain, ftype)
     else:
-        n_stream = int(np.prod(leading_shape))
-        if offset.shape != leading_shape:
-            raise ValueError(f"Offset array has shape {offset.shape}, expected shape {leading_shape}")
-        if gain.shape != leading_shape:
-            raise ValueError(f"Gain array has shape {gain.shape}, expected shape {leading_shape}")
-    stream_size = idata.shape[-1]
-    result = (wrap_int64_to_float64 if is_i64 else wrap_int32_to_float32)(
-        np.ascontiguousarray(idata).reshape((-1,)), n_stream, stream_size, offset.reshape((-1,)), gain.reshape((-1,))
-    )
-    return result.reshape(idata.shape)
+        for name, arr in (("Offset", offset), ("Gain", gain)):
+            if arr.shape != lead:
+                raise ValueError(f"{name} array has shape {arr.shape}, expected shape {lead}")
+    flat = globals()[restore](np.ascontiguousarray(idata).reshape(-1), n_stream, stream_size, offset.reshape(-1), gain.reshape(-1))
+    return flat.reshape(idata.shape)
 
 
 def keep_select(keep, stream_starts, stream_nbytes):

