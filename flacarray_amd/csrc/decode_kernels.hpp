@@ -1107,7 +1107,9 @@ __global__ __launch_bounds__(64) FA_K7_WAVES_ATTR void decode_frames_kernel(Deco
             hbw = 0;
         }
         constexpr int kRowsPerPass = 64 / kTileG;
-        if (!F32 && all_al && tbase >= lo_max && tbase + kTileW <= hi_min) {
+        if (all_al && tbase >= lo_max && tbase + kTileW <= hi_min) {
+            // the whole tile lies inside every row's range and every row is 16-byte aligned: plain vector stores (for the
+            // float32 output too: the restore of utils.c:364 with the row's offset and 1 / gain)
 #pragma unroll
             for (int it = 0; it < kTileG; ++it) {
                 const int r = it * kRowsPerPass + (lane / kTileG);
@@ -1116,7 +1118,17 @@ __global__ __launch_bounds__(64) FA_K7_WAVES_ATTR void decode_frames_kernel(Deco
                 const int rsw = r ^ (cg * kTileSwz);
                 const int4 v = make_int4(tile[(cb + 0) * kLaneStride + rsw], tile[(cb + 1) * kLaneStride + rsw],
                                          tile[(cb + 2) * kLaneStride + rsw], tile[(cb + 3) * kLaneStride + rsw]);
-                *reinterpret_cast<int4*>(a.out_i32 + rout[it] + tbase + cb) = v;
+                if constexpr (F32) {
+                    const float2 fg = row_fg[r];
+                    float4 o;
+                    o.x = __fadd_rn(fg.x, __fmul_rn(fg.y, (float)v.x));
+                    o.y = __fadd_rn(fg.x, __fmul_rn(fg.y, (float)v.y));
+                    o.z = __fadd_rn(fg.x, __fmul_rn(fg.y, (float)v.z));
+                    o.w = __fadd_rn(fg.x, __fmul_rn(fg.y, (float)v.w));
+                    *reinterpret_cast<float4*>(a.out_f32 + rout[it] + tbase + cb) = o;
+                } else {
+                    *reinterpret_cast<int4*>(a.out_i32 + rout[it] + tbase + cb) = v;
+                }
             }
             __builtin_amdgcn_wave_barrier();
             return;

@@ -42,13 +42,21 @@ constexpr int kFRingBlocks = kFRingWords / 64;
 // completed 256-byte blocks are written out once this many are pending: a larger ring delays the first flush -- the
 // point where the frame's byte offset must be known -- and always keeps room for the longest row (6 blocks) plus a
 // partial block
-constexpr int kFFlushHold = kFRingBlocks - 7;
+#ifndef FA_F_ROW8
+#define FA_F_ROW8 1  // the row writer takes 8 samples per lane (rows of 512) instead of 4 (rows of 256)
+#endif
+constexpr int kFRowBlocks = FA_F_ROW8 ? 12 : 6;  // longest row in 256-byte blocks (two spec rows of 12288 bits each)
+constexpr int kFFlushHold = kFRingBlocks - kFRowBlocks - 1;
+static_assert(kFFlushHold >= 1, "the ring must hold the longest row and a partial block beside what waits to be flushed");
 constexpr int kFWaveWords = kFSmpWords + kFRingWords + 4 + 16;  // image, ring, mirror word (+pad), Rice parameter table
 constexpr int kFWaves = 4;                                      // wavefronts (frames) per workgroup
 constexpr int kFCrcSlice = 1024;                                // 4 x 256 transformed slicing tables (uint16)
 constexpr int kFCrcXpow = 520;                                  // x^(8 (i - 255)) mod P, i < 520
 #ifndef FA_F_SLEEP
 #define FA_F_SLEEP 8  // x 64 cycles between two polls of the look-back
+#endif
+#ifndef FA_F_WBATCH
+#define FA_F_WBATCH 4  // groups of 4 samples whose window values are in flight together in the lag loops
 #endif
 #ifndef FA_F_WAVES
 #define FA_F_WAVES 3  // waves per SIMD the register allocation aims at
@@ -635,12 +643,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
                 }
                 // window values four groups at a time (16 registers in flight, not 32: the kernel lives at 168)
 #pragma unroll
-                for (int tb = 0; tb < 8; tb += 4) {
-                    float4 wv[4];
+                for (int tb = 0; tb < 8; tb += FA_F_WBATCH) {
+                    float4 wv[FA_F_WBATCH];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) wv[t] = *reinterpret_cast<const float4*>(win + g0 + 4 * (tb + t));
+                    for (int t = 0; t < FA_F_WBATCH; ++t) wv[t] = *reinterpret_cast<const float4*>(win + g0 + 4 * (tb + t));
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
+                    for (int t = 0; t < FA_F_WBATCH; ++t) {
                         lag_group(*reinterpret_cast<const int4*>(&smp[K ^ (4 * (tb + t))]), wv[t]);
                         search_stage(tb + t);
                     }
@@ -657,12 +665,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
 #pragma unroll
                 for (int j = 0; j < MLO; ++j) hist[j] = (double)hs[j] * (double)win[g0 - 1 - j];
 #pragma unroll
-                for (int tb = 0; tb < 8; tb += 4) {
-                    float4 wv[4];
+                for (int tb = 0; tb < 8; tb += FA_F_WBATCH) {
+                    float4 wv[FA_F_WBATCH];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) wv[t] = *reinterpret_cast<const float4*>(win + g0 + 4 * (tb + t));
+                    for (int t = 0; t < FA_F_WBATCH; ++t) wv[t] = *reinterpret_cast<const float4*>(win + g0 + 4 * (tb + t));
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
+                    for (int t = 0; t < FA_F_WBATCH; ++t) {
                         lag_group(Bv[tb + t], wv[t]);
                         search_stage(8 + tb + t);
                     }
@@ -1208,6 +1216,75 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
                 if (R.newp) put_bits(p0, k, (uint32_t)plen);
             }
         };
+#if FA_F_ROW8
+        // Rows of 512 samples, 8 consecutive samples per lane (two 16-byte units of one chunk): the per-row work -- the
+        // scan of the lane lengths, the parameter lookup, the flush test -- is paid 8 times per frame instead of 16.
+        // (The 12288-bit cap of the specification stays a property of 256-sample rows; the sizing pass checked it.)
+        {
+            const int cb = (ln_ >> 2) + 1;
+            const int r8a = 32 * cb + 4 * ((2 * (ln_ & 3)) ^ (cb & 7)), r8b = 32 * cb + 4 * ((2 * (ln_ & 3) + 1) ^ (cb & 7));
+            auto row8 = [&](auto first_tag, int j) __attribute__((always_inline)) {
+                constexpr bool FIRST = decltype(first_tag)::value;  // row 0: warm-up samples carry no code
+                const uint32_t gb = (uint32_t)(512 * j + 8 * lane);
+                const int4 va = *reinterpret_cast<const int4*>(&smp[r8a + 512 * (j & 3)]);
+                const int4 vb = *reinterpret_cast<const int4*>(&smp[r8b + 512 * (j & 3)]);
+                const uint32_t us[8] = {(uint32_t)va.x, (uint32_t)va.y, (uint32_t)va.z, (uint32_t)va.w,
+                                        (uint32_t)vb.x, (uint32_t)vb.y, (uint32_t)vb.z, (uint32_t)vb.w};
+                const uint32_t pidx = gb >> l2ps;
+                const uint32_t k = kpar[pidx], kp1 = k + 1u;
+                // partition 0 opens at sample `order`, the others at multiples of the partition size (>= 64)
+                const uint32_t pstart = (pidx == 0u) ? (uint32_t)order : (pidx << l2ps);
+                const bool newp = FIRST ? (gb <= pstart && pstart < gb + 8u) : ((gb & (ps - 1u)) == 0u);
+                uint32_t q[8];
+                uint32_t len = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    uint32_t qq = us[e] >> k;
+                    if constexpr (FIRST) {
+                        const uint32_t gi = gb + (uint32_t)e;
+                        const bool valid = gi >= (uint32_t)order;
+                        qq += (gi == pstart) ? (uint32_t)plen : 0u;
+                        q[e] = valid ? qq : 0xffffffffu;  // marks "no code"
+                        len += valid ? (qq + kp1) : 0u;
+                    } else {
+                        if (e == 0) qq += newp ? (uint32_t)plen : 0u;
+                        q[e] = qq;
+                        len += qq;
+                    }
+                }
+                const uint32_t lane_len = FIRST ? len : (len + 8u * kp1);
+                const uint32_t incl = wave_incl_scan_u32(lane_len);
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                const uint32_t onek = 1u << k, mask = onek - 1u;
+                const uint32_t p0 = pos + incl - lane_len;
+                uint32_t p = p0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if constexpr (FIRST) {
+                        if (q[e] != 0xffffffffu) {
+                            if (gb + (uint32_t)e == pstart) put_bits(p, k, (uint32_t)plen);
+                            put_bits(p + q[e], onek | (us[e] & mask), kp1);
+                            p += q[e] + kp1;
+                        }
+                    } else {
+                        put_bits(p + q[e], onek | (us[e] & mask), kp1);
+                        p += q[e] + kp1;
+                    }
+                }
+                if constexpr (!FIRST) {
+                    if (newp) put_bits(p0, k, (uint32_t)plen);
+                }
+                pos += total;
+                flush_blocks();
+            };
+            row8(std::true_type{}, 0);
+#pragma unroll 1
+            for (int j = 1; j < 8; ++j) {
+                if (j == 4) store_b();  // rows 0..3 (the first half) have been read: the second half takes their place
+                row8(std::false_type{}, j);
+            }
+        }
+#else
         {
             RowPrep r0;
             rice_prep(std::true_type{}, 0, r0);
@@ -1233,6 +1310,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
                 flush_blocks();
             }
         }
+#endif
     }
 
     FA_STAMP(11);
