@@ -69,6 +69,8 @@ struct FusedArgs {
     const float* f_gains;
     int64_t n_stream, stream_size, nframes, total_frames;
     int32_t max_lpc_order, max_porder, precision, pmax_full;
+    int32_t tail_bs;        // samples of a stream's last frame; below 4096 that frame is not this kernel's (the slot encoder
+                            // wrote it and published its size before the launch; the scanner places it like any other)
     double escale_full;     // 0.5 / 4096
     const float* win;       // [4096] tukey(0.5)
     const uint4* hdr;       // [nframes] frame header fields by frame number (frame_header_entry)
@@ -313,6 +315,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
 
     const int64_t s = (int64_t)((uint32_t)g / (uint32_t)a.nframes);
     const int64_t f = g - s * a.nframes;
+    if (f == a.nframes - 1 && a.tail_bs != kMaxBlock) return;  // a short last frame: encoded by the slot kernel
     constexpr int bs = kMaxBlock;
     const int32_t* src = a.data + (s * a.stream_size + f * (int64_t)bs);
     float q_off = 0.0f, q_gain = 0.0f;
@@ -1408,6 +1411,31 @@ __global__ __launch_bounds__(256) void fused_finish_kernel(uint8_t* __restrict__
     }
 }
 
+// short last frames (stream lengths that are not a multiple of 4096): sizes in before K3F, bytes moved after it.
+// tail_publish: size_pub of every stream's last frame from the slot encoder's frame_bytes.
+// tail_prep: after K3F every frame has its offset -- arguments for compact_frames_kernel, called with "one frame per
+// stream" geometry (its header size is then 64 bytes, folded into the offsets), and frame_abs for the stream headers.
+FA_GLOBAL __global__ __launch_bounds__(256) void fused_tail_publish_kernel(const uint32_t* __restrict__ frame_bytes, uint32_t* __restrict__ size_pub,
+                                                                           int64_t n_stream, int64_t nframes) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_stream) return;
+    const int64_t g = s * nframes + nframes - 1;
+    __hip_atomic_store(size_pub + g, 0x80000000u | frame_bytes[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+FA_GLOBAL __global__ __launch_bounds__(256) void fused_tail_prep_kernel(const unsigned long long* __restrict__ off_pub,
+                                                                        const uint32_t* __restrict__ frame_bytes, int64_t n_stream, int64_t nframes,
+                                                                        int64_t* __restrict__ frame_abs, uint32_t* __restrict__ tail_bytes,
+                                                                        int64_t* __restrict__ tail_off, int64_t* __restrict__ zeros) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_stream) return;
+    const int64_t g = s * nframes + nframes - 1;
+    const int64_t off = (int64_t)off_pub[g];
+    frame_abs[g] = off;
+    tail_bytes[s] = frame_bytes[g];
+    tail_off[s] = off - stream_header_bytes(1);
+    zeros[s] = 0;
+}
+
 #endif  // the kernels
 
 // host-side launchers (defined in the unit that holds the kernels: csrc/fused_unit.hip in the shipped build, compiled
@@ -1441,11 +1469,29 @@ void launch_fused_encode(hipStream_t st, const FusedArgs& a, bool f32)
 ;
 #endif
 void launch_fused_finish(hipStream_t st, uint8_t* out, const int64_t* frame_abs, const uint32_t* frame_bytes, int64_t n_stream,
-                         int64_t nframes, int64_t stream_size, int64_t hb, int64_t* starts, int64_t* nbytes, int64_t* total)
+                         int64_t nframes, int64_t stream_size, int32_t tail_bs, int64_t hb, int64_t* starts, int64_t* nbytes, int64_t* total)
 #if defined(FA_UNIT_FUSED) || !defined(FA_SPLIT_UNITS)
 {
     hipLaunchKernelGGL(fused_finish_kernel, dim3((unsigned)n_stream), dim3(256), 0, st, out, frame_abs, frame_bytes, n_stream, nframes,
-                       stream_size, (int32_t)kMaxBlock, (int32_t)kMaxBlock, 1, hb, starts, nbytes, total);
+                       stream_size, (int32_t)kMaxBlock, tail_bs, 1, hb, starts, nbytes, total);
+}
+#else
+;
+#endif
+void launch_fused_tail_publish(hipStream_t st, const uint32_t* frame_bytes, uint32_t* size_pub, int64_t n_stream, int64_t nframes)
+#if defined(FA_UNIT_FUSED) || !defined(FA_SPLIT_UNITS)
+{
+    hipLaunchKernelGGL(fused_tail_publish_kernel, dim3((unsigned)((n_stream + 255) / 256)), dim3(256), 0, st, frame_bytes, size_pub, n_stream, nframes);
+}
+#else
+;
+#endif
+void launch_fused_tail_prep(hipStream_t st, const unsigned long long* off_pub, const uint32_t* frame_bytes, int64_t n_stream, int64_t nframes,
+                            int64_t* frame_abs, uint32_t* tail_bytes, int64_t* tail_off, int64_t* zeros)
+#if defined(FA_UNIT_FUSED) || !defined(FA_SPLIT_UNITS)
+{
+    hipLaunchKernelGGL(fused_tail_prep_kernel, dim3((unsigned)((n_stream + 255) / 256)), dim3(256), 0, st, off_pub, frame_bytes, n_stream, nframes,
+                       frame_abs, tail_bytes, tail_off, zeros);
 }
 #else
 ;

@@ -57,6 +57,8 @@ struct EncodeArgs {
     const uint4* hdr;       // [nframes] frame header fields by frame number (see frame_header_entry)
     int32_t pmax_full, pmax_tail;  // max_porder_for(B / tail_bs, max_porder, 0): the part that does not depend on the predictor order
     double escale_full, escale_tail;  // 0.5 / blocksize (best_lpc_order's error scale), divided once on the host
+    int32_t tail_only;  // 1: the grid is one workgroup per STREAM and encodes only its last frame, into slot [stream] (the
+                        // single-pass encoder takes the full frames, encode_fused.hpp)
 };
 
 // Frame header of frame number f (RFC 9639 9.1) as the fields the preamble writer ORs into the ring.
@@ -544,7 +546,7 @@ FA_GLOBAL __global__ __launch_bounds__(64) FA_K3_WAVES_ATTR void encode_frames_k
     (void)psum;
 
     const int lane = threadIdx.x;
-    const int64_t g = blockIdx.x;
+    const int64_t g = a.tail_only ? ((int64_t)blockIdx.x * a.nframes + a.nframes - 1) : (int64_t)blockIdx.x;
     // (the host keeps n_stream * nframes below 2^31: a 32-bit division, not the 64-bit software one)
     const int64_t s = (int64_t)((uint32_t)g / (uint32_t)a.nframes);
     const int64_t f = g - s * a.nframes;
@@ -556,7 +558,7 @@ FA_GLOBAL __global__ __launch_bounds__(64) FA_K3_WAVES_ATTR void encode_frames_k
 
     FA_STAMP_INIT;
     // frame-level writer state: bit position, flushed 256-byte blocks, the zeroed ring
-    uint8_t* slot = a.slots + (size_t)g * (size_t)a.slot_stride;
+    uint8_t* slot = a.slots + (size_t)(a.tail_only ? (int64_t)blockIdx.x : g) * (size_t)a.slot_stride;
     uint32_t total_bytes = 0;
     uint32_t pos = 0;
     uint32_t blocks_flushed = 0;

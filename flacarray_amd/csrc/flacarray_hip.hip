@@ -281,13 +281,17 @@ struct FusedPlan {
     LevelParams P;
     int64_t nf, F, hb;
     size_t off_fbytes, off_fabs, off_zero, off_size, off_off, off_ticket, zero_bytes, off_total, total;
+    size_t off_tslots, off_tbytes, off_toff, off_tzero;  // short last frames: slots and the compaction's arguments
+    int tail_bs;
     int64_t capacity;
 };
 
-bool fused_geometry(int64_t n_stream, int64_t stream_size, uint32_t level) {
+// f32: float32 input (quantised in the staging load of K3F only: whole frames).  int32 streams may end in a short
+// frame -- the slot encoder writes those, K3F the rest -- if every frame still starts on a 16-byte boundary.
+bool fused_geometry(int64_t n_stream, int64_t stream_size, uint32_t level, bool f32 = false) {
     if (level < 3 || level > 8 || n_stream <= 0 || stream_size <= 0) return false;
-    if (stream_size % kMaxBlock != 0) return false;
-    const int64_t nf = stream_size / kMaxBlock;
+    if (stream_size % kMaxBlock != 0 && (f32 || stream_size % 4 != 0 || stream_size < 2 * kMaxBlock)) return false;
+    const int64_t nf = (stream_size + kMaxBlock - 1) / kMaxBlock;
     if (18 * nf >= (1 << 24)) return false;
     if (nf > 0x7fffffffLL / n_stream) return false;
     return std::getenv("FLACARRAY_HIP_SLOTS") == nullptr;  // diagnostic: force the slot path (K3 + K4 + K5)
@@ -295,7 +299,8 @@ bool fused_geometry(int64_t n_stream, int64_t stream_size, uint32_t level) {
 
 void make_fused_plan(int64_t n_stream, int64_t stream_size, uint32_t level, FusedPlan* pl) {
     pl->P = level_params(level);
-    pl->nf = stream_size / kMaxBlock;
+    pl->nf = (stream_size + kMaxBlock - 1) / kMaxBlock;
+    pl->tail_bs = (int)(stream_size - (pl->nf - 1) * (int64_t)kMaxBlock);
     pl->F = n_stream * pl->nf;
     pl->hb = stream_header_bytes(pl->nf);
     size_t o = 0;
@@ -307,6 +312,13 @@ void make_fused_plan(int64_t n_stream, int64_t stream_size, uint32_t level, Fuse
     pl->off_ticket = o; o = align_up(o + 16, 256);  // ticket word, error flags
     pl->zero_bytes = o - pl->off_zero;
     pl->off_total = o;  o = align_up(o + 8, 256);
+    pl->off_tslots = pl->off_tbytes = pl->off_toff = pl->off_tzero = o;
+    if (pl->tail_bs != kMaxBlock) {
+        pl->off_tslots = o; o = align_up(o + (size_t)n_stream * (size_t)kSlotBytes + 4096, 256);  // (+ the compaction's group reads)
+        pl->off_tbytes = o; o = align_up(o + (size_t)n_stream * 4, 256);
+        pl->off_toff = o;   o = align_up(o + (size_t)n_stream * 8, 256);
+        pl->off_tzero = o;  o = align_up(o + (size_t)n_stream * 8, 256);
+    }
     pl->total = o;
     pl->capacity = pl->F * (int64_t)kSlotBytes + n_stream * pl->hb;
 }
@@ -596,6 +608,7 @@ static int encode_device_begin(const int32_t* d_data, int nch, int64_t n_stream,
     char* ws = reinterpret_cast<char*>(d_workspace);
     prof_begin(3, st);
     EncodeArgs a;
+    std::memset(&a, 0, sizeof a);
     a.data = d_data; a.n_stream = n_stream; a.stream_size = stream_size; a.nframes = pl.nf;
     a.B = pl.P.blocksize; a.tail_bs = pl.tail_bs;
     a.max_lpc_order = pl.P.max_lpc_order; a.max_porder = pl.P.max_porder; a.precision = pl.P.qlp_precision;
@@ -783,6 +796,8 @@ static int fused_encode_run(const void* d_data, bool f32, const float* d_quanta,
     a.max_lpc_order = pl.P.max_lpc_order; a.max_porder = pl.P.max_porder; a.precision = pl.P.qlp_precision;
     a.pmax_full = max_porder_for(kMaxBlock, a.max_porder, 0);
     a.escale_full = 0.5 / (double)kMaxBlock;
+    a.tail_bs = pl.tail_bs;
+    const bool tails = (pl.tail_bs != kMaxBlock);
     int rc = get_window(kMaxBlock, &a.win);
     if (rc) return rc;
     rc = get_crc_tab_fused(&a.crc_tab);
@@ -791,13 +806,14 @@ static int fused_encode_run(const void* d_data, bool f32, const float* d_quanta,
         void* dp = nullptr;
         rc = get_scratch(9, (size_t)pl.nf * sizeof(uint4) + 256, &dp);
         if (rc) return rc;
-        if (ds_->c_nf != pl.nf || ds_->c_B != kMaxBlock || ds_->c_tail != kMaxBlock || ds_->c_nch != 1 || ds_->c_dp != dp ||
+        if (ds_->c_nf != pl.nf || ds_->c_B != kMaxBlock || ds_->c_tail != pl.tail_bs || ds_->c_nch != 1 || ds_->c_dp != dp ||
             ds_->c_epoch != ds_->scratch_epoch) {
             ds_->h_hdr.resize((size_t)pl.nf);
-            for (int64_t f = 0; f < pl.nf; ++f) ds_->h_hdr[(size_t)f] = frame_header_entry((uint64_t)f, kMaxBlock, 1);
+            for (int64_t f = 0; f < pl.nf; ++f)
+                ds_->h_hdr[(size_t)f] = frame_header_entry((uint64_t)f, (f == pl.nf - 1) ? pl.tail_bs : kMaxBlock, 1);
             FA_HIP_TRY(hipMemcpyAsync(dp, ds_->h_hdr.data(), (size_t)pl.nf * sizeof(uint4), hipMemcpyHostToDevice, st));
             FA_HIP_TRY(hipStreamSynchronize(st));
-            ds_->c_nf = pl.nf; ds_->c_B = kMaxBlock; ds_->c_tail = kMaxBlock; ds_->c_nch = 1; ds_->c_dp = dp; ds_->c_epoch = ds_->scratch_epoch;
+            ds_->c_nf = pl.nf; ds_->c_B = kMaxBlock; ds_->c_tail = pl.tail_bs; ds_->c_nch = 1; ds_->c_dp = dp; ds_->c_epoch = ds_->scratch_epoch;
         }
         a.hdr = reinterpret_cast<const uint4*>(dp);
     }
@@ -819,11 +835,50 @@ static int fused_encode_run(const void* d_data, bool f32, const float* d_quanta,
         }
     }
 #endif
+    if (tails) {
+        // the short last frame of every stream: the slot encoder (one workgroup per stream) writes it to a slot and its
+        // size goes into size_pub, so that the scanner places it between its neighbours like any other frame
+        EncodeArgs t;
+        std::memset(&t, 0, sizeof t);
+        t.data = a.data; t.n_stream = n_stream; t.stream_size = stream_size; t.nframes = pl.nf; t.B = kMaxBlock; t.tail_bs = pl.tail_bs;
+        t.max_lpc_order = a.max_lpc_order; t.max_porder = a.max_porder; t.precision = a.precision;
+        t.win = a.win;
+        rc = get_window(pl.tail_bs, &t.win_tail);
+        if (rc) return rc;
+        t.slots = reinterpret_cast<uint8_t*>(ws + pl.off_tslots); t.slot_stride = kSlotBytes;
+        t.frame_bytes = a.frame_bytes; t.info = a.info; t.hdr = a.hdr;
+        t.pmax_full = a.pmax_full; t.pmax_tail = max_porder_for(pl.tail_bs, a.max_porder, 0);
+        t.escale_full = a.escale_full; t.escale_tail = 0.5 / (double)pl.tail_bs;
+        t.tail_only = 1;
+#ifdef FA_DEV_MINIMAL
+        launch_encode<8, 1>(t, n_stream, st);
+#else
+        switch (t.max_lpc_order) {
+            case 6: launch_encode<6, 1>(t, n_stream, st); break;
+            case 8: launch_encode<8, 1>(t, n_stream, st); break;
+            default: launch_encode<12, 1>(t, n_stream, st); break;
+        }
+#endif
+        launch_fused_tail_publish(st, a.frame_bytes, a.size_pub, n_stream, pl.nf);
+    }
     prof_begin(0, st);
     launch_fused_encode(st, a, f32);
     prof_end(0, st);
     int64_t* d_total = reinterpret_cast<int64_t*>(ws + pl.off_total);
-    launch_fused_finish(st, d_bytes, a.frame_abs, a.frame_bytes, n_stream, pl.nf, stream_size, pl.hb, d_starts, d_nbytes, d_total);
+    if (tails) {
+        // every frame has its offset now: move the short frames from their slots (byte-shifted copy + CRC-16, K5)
+        uint32_t* tb = reinterpret_cast<uint32_t*>(ws + pl.off_tbytes);
+        int64_t* toff = reinterpret_cast<int64_t*>(ws + pl.off_toff);
+        int64_t* tzero = reinterpret_cast<int64_t*>(ws + pl.off_tzero);
+        launch_fused_tail_prep(st, a.off_pub, a.frame_bytes, n_stream, pl.nf, a.frame_abs, tb, toff, tzero);
+        const uint16_t* crc5 = nullptr;
+        rc = get_crc_tab(&crc5);
+        if (rc) return rc;
+        int64_t nblk = (n_stream + 3) / 4;
+        if (nblk > 32768) nblk = 32768;
+        launch_compact_frames(st, nblk, reinterpret_cast<const uint8_t*>(ws + pl.off_tslots), tb, toff, tzero, 1, n_stream, crc5, d_bytes, kSlotBytes);
+    }
+    launch_fused_finish(st, d_bytes, a.frame_abs, a.frame_bytes, n_stream, pl.nf, stream_size, (int32_t)pl.tail_bs, pl.hb, d_starts, d_nbytes, d_total);
     prof_end(3, st);
     int h_err = 0, h_nan = 0;
     FA_HIP_TRY(hipMemcpyAsync(&h_err, a.err, 4, hipMemcpyDeviceToHost, st));
@@ -868,7 +923,7 @@ int fa_encode_f32_device(const float* d_data, int64_t n_stream, int64_t stream_s
     if (stream_size <= 0) return FA_ERROR_ZERO_STREAMSIZE;
     if (!d_offsets || !d_gains) return FA_ERROR_CONVERT_TYPE;
     // (other geometries: quantise with fa_float32_to_int32_device, then encode the integers)
-    if (!fused_geometry(n_stream, stream_size, level) || (reinterpret_cast<uintptr_t>(d_data) & 15)) return FA_ERROR_ENCODE_INIT;
+    if (!fused_geometry(n_stream, stream_size, level, true) || (reinterpret_cast<uintptr_t>(d_data) & 15)) return FA_ERROR_ENCODE_INIT;
     return fused_encode_run(d_data, true, d_quanta, d_offsets, d_gains, n_stream, stream_size, level, d_workspace, workspace_bytes, d_bytes,
                             capacity_bytes, d_starts, d_nbytes, h_total_bytes, d_info, stream);
 }

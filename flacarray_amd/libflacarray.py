@@ -251,7 +251,8 @@ def encode_flac_device(data, level=5, workspace=None, return_info=False, compact
     device, starts/nbytes with the leading shape of `data` (at least 1-D) -- the device-resident
     analogue of encode_flac (libflacarray.pyx:529-594).
 
-    int32 input whose stream length is a multiple of 4096 (levels 3-8) takes the single-pass kernel: the frames are
+    int32 input at levels 3-8 whose streams are at least two frames long and a multiple of 4 samples takes the
+    single-pass kernel (a short last frame goes through a slot and is moved into place afterwards): the frames are
     written straight to their final offsets inside a buffer sized for the worst case, and `compressed` is the view
     [0, total) of that buffer (it keeps the whole buffer alive; `compact=True` returns an exact-size copy instead).
     Everything else runs the slot sequence (K3, K4, K5) and returns an exact-size tensor.
@@ -353,7 +354,7 @@ def encode_flac_device_f32(data, quanta=None, level=5, workspace=None, compact=F
         if q.numel() != n_stream:
             raise RuntimeError("quanta must have one entry per stream")
     L = _lib.lib()
-    if not (data.data_ptr() % 16 == 0 and L.fa_encode_single_pass_supported(n_stream, stream_size, level)):
+    if not (data.data_ptr() % 16 == 0 and stream_size % 4096 == 0 and L.fa_encode_single_pass_supported(n_stream, stream_size, level)):
         ints, offsets, gains = float32_to_int32_device(data, q)
         comp, st, nb = encode_flac_device(ints, level=level, workspace=workspace, compact=compact)
         return comp, st, nb, offsets, gains

@@ -107,8 +107,9 @@ int fa_encode_i32_device_begin(const int32_t* d_data, int64_t n_stream, int64_t 
 int fa_encode_i32_device_finish(int64_t n_stream, int64_t stream_size, uint32_t level, void* d_workspace,
                                 const int64_t* d_starts, unsigned char* d_bytes, void* stream);
 
-/* Single-pass encode.  When the geometry allows it (levels 3-8, stream_size a multiple of 4096, 16-byte aligned
- * input: fa_encode_single_pass_supported) ONE kernel analyses every frame, sizes it, finds its byte offset by a
+/* Single-pass encode.  When the geometry allows it (levels 3-8, 16-byte aligned input, stream_size a multiple of 4096 --
+ * or a multiple of 4 and at least 8192, in which case every stream's short last frame takes a detour through a slot:
+ * fa_encode_single_pass_supported) ONE kernel analyses every full frame, sizes it, finds its byte offset by a
  * look-back over the frames before it and writes it -- CRC-16 included -- to its final place in d_bytes; there is
  * no per-frame slot and no compaction pass.  The caller provides d_bytes with fa_encode_capacity_bytes() bytes
  * (worst case: every frame VERBATIM) and a workspace of fa_encode_single_pass_workspace_bytes(); the encoded
