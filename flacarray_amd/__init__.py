@@ -10,6 +10,7 @@ from .array import FlacArray
 from .compress import array_compress
 from .decompress import array_decompress, array_decompress_slice
 from .libflacarray import (
+    DeviceDecodeIndex,
     decode_flac,
     decode_flac_device,
     decode_slices_device,
@@ -28,6 +29,7 @@ __version__ = "0.1.0"
 
 __all__ = [
     "FlacArray",
+    "DeviceDecodeIndex",
     "array_compress",
     "array_decompress",
     "array_decompress_slice",

@@ -40,6 +40,9 @@ SYMBOLS = [
     "fa_decode_slices_i64_device",
     "fa_float32_to_int32_device",
     "fa_int32_to_float32_device",
+    "fa_decode_index_create",
+    "fa_decode_index_destroy",
+    "fa_decode_indexed",
     "fa_set_decode_verify",
     "fa_profile_enable",
     "fa_profile_last",
@@ -111,6 +114,12 @@ def lib():
     L.fa_float32_to_int32_device.restype = cint
     L.fa_int32_to_float32_device.argtypes = [vp, i64, i64, vp, vp, vp, vp]
     L.fa_int32_to_float32_device.restype = cint
+    L.fa_decode_index_create.argtypes = [vp, i64, vp, vp, i64, i64, cint, ctypes.POINTER(vp), vp]
+    L.fa_decode_index_create.restype = cint
+    L.fa_decode_index_destroy.argtypes = [vp]
+    L.fa_decode_index_destroy.restype = None
+    L.fa_decode_indexed.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.fa_decode_indexed.restype = cint
     L.fa_set_decode_verify.argtypes = [cint]
     L.fa_set_decode_verify.restype = cint
     L.fa_profile_enable.argtypes = [cint]

@@ -267,8 +267,19 @@ class FlacArray:
         self._resident = res
         return self
 
+    def _index(self):
+        """The store's decode index (stream headers parsed, frame offsets tabulated once), built on first use."""
+        res = self._resident
+        if res.get("index") is None:
+            from .libflacarray import DeviceDecodeIndex
+
+            res["index"] = DeviceDecodeIndex(res["compressed"], res["starts"], res["nbytes"], self._stream_size, is_int64=self._is_int64)
+        return res["index"]
+
     def release_device(self):
-        """Drop the HBM copy made by to_device()."""
+        """Drop the HBM copy made by to_device() (and its decode index)."""
+        if self._resident is not None and self._resident.get("index") is not None:
+            self._resident["index"].close()
         self._resident = None
         return self
 
@@ -281,26 +292,23 @@ class FlacArray:
         Returns (2-D result: kept streams x samples, list of kept multi-indices or None)."""
         import torch
 
-        from .libflacarray import decode_flac_device
-
         res = self._resident
         indices = None
-        st, nb, off, gain = res["starts"], res["nbytes"], res["offsets"], res["gains"]
-        if keep is not None:
+        off, gain = res["offsets"], res["gains"]
+        if keep is None:
+            out = self._index().decode(first, last, offsets=off, gains=gain)
+        else:
             if keep.shape != tuple(self._leading_shape):
                 raise RuntimeError("The keep array should have the same shape as stream_starts")
             sel = np.flatnonzero(np.asarray(keep).reshape(-1))
             indices = list(zip(*(ax.tolist() for ax in np.unravel_index(sel, self._leading_shape))))
-            idx = torch.from_numpy(sel).to(res["device"])
-            st, nb = st[idx].contiguous(), nb[idx].contiguous()
-            if off is not None:
-                off, gain = off[idx].contiguous(), gain[idx].contiguous()
-        if st.numel() == 0:
-            n = self._stream_size if (first < 0 or last < 0) else last - first
-            out = torch.zeros((0, n), dtype=getattr(torch, self._typestr), device=res["device"])
-        else:
-            out = decode_flac_device(res["compressed"], st, nb, self._stream_size, first, last, offsets=off, gains=gain,
-                                     is_int64=self._is_int64)
+            f0, n = (0, self._stream_size) if (first < 0 or last < 0) else (first, last - first)
+            if sel.size == 0:
+                out = torch.zeros((0, n), dtype=getattr(torch, self._typestr), device=res["device"])
+            else:
+                # the kept streams as one batch of slices against the index (one launch, nothing re-parsed)
+                flat, _ = self._index().decode_slices(sel, np.full(sel.size, f0, np.int64), np.full(sel.size, n, np.int64), offsets=off, gains=gain)
+                out = flat.reshape(sel.size, n)
         return (out if as_tensor else out.cpu().numpy()), indices
 
     def __getitem__(self, raw_key):
@@ -406,11 +414,12 @@ class FlacArray:
             if self._stream_offsets is not None:
                 off = torch.from_numpy(np.ascontiguousarray(self._stream_offsets).reshape(-1))
                 gain = torch.from_numpy(np.ascontiguousarray(self._stream_gains).reshape(-1))
+        if res is not None:
+            out, out_off = self._index().decode_slices(streams, first, count, offsets=res["offsets"], gains=res["gains"])
         else:
-            comp, st, nb, off, gain = res["compressed"], res["starts"], res["nbytes"], res["offsets"], res["gains"]
-        out, out_off = decode_slices_device(
-            comp, st, nb, self._stream_size, streams, first, count, offsets=off, gains=gain, is_int64=self._is_int64
-        )
+            out, out_off = decode_slices_device(
+                comp, st, nb, self._stream_size, streams, first, count, offsets=off, gains=gain, is_int64=self._is_int64
+            )
         if as_tensor:
             return out, out_off
         flat = out.cpu().numpy()

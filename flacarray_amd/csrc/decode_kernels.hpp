@@ -977,16 +977,18 @@ __global__ __launch_bounds__(64) FA_K7_WAVES_ATTR void decode_frames_kernel(Deco
     }
     // a tile that lies inside every row's valid range and whose rows are 16-byte aligned in the
     // output is stored without per-element tests (the common case: whole frames of whole streams)
-    int lo_max = lo, hi_min = hi;
+    int lo_max = lo, hi_min = hi, hi_max = hi;
     bool row_al = out_aligned && ((row0 & 3) == 0);
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        const int o1 = __shfl_xor(lo_max, off, 64), o2 = __shfl_xor(hi_min, off, 64);
+        const int o1 = __shfl_xor(lo_max, off, 64), o2 = __shfl_xor(hi_min, off, 64), o3 = __shfl_xor(hi_max, off, 64);
         lo_max = o1 > lo_max ? o1 : lo_max;
         hi_min = o2 < hi_min ? o2 : hi_min;
+        hi_max = o3 > hi_max ? o3 : hi_max;
     }
     lo_max = __builtin_amdgcn_readfirstlane(lo_max);
     hi_min = __builtin_amdgcn_readfirstlane(hi_min);
+    hi_max = __builtin_amdgcn_readfirstlane(hi_max);
     const bool all_al = __all(row_al);
     // chunk `pend_ci` is requested one chunk-time before it is stored into the ring
     uint32_t pend_ci = next_chunk;
@@ -1195,10 +1197,18 @@ __global__ __launch_bounds__(64) FA_K7_WAVES_ATTR void decode_frames_kernel(Deco
     // guarded head (warm-up zone), unguarded main part, guarded tail (frames shorter than B).
     // The two guarded ranges share one loop so that the guarded body is instantiated once.
     constexpr int kStep = (MACRO > kTileW) ? MACRO : kTileW;
-    const int end = (bs_max + kStep - 1) / kStep * kStep;  // the last tile is stored whole
+    int end = (bs_max + kStep - 1) / kStep * kStep;  // the last tile is stored whole
+    if (chn == NCH - 1) {
+        // nothing behind the last sample any lane of this wave has to deliver is decoded (a short read from the
+        // head of a frame costs what it reads, not the frame); a first channel is always walked to its end,
+        // because that is where the second sub-frame starts
+        const int need = (hi_max + kStep - 1) / kStep * kStep;
+        if (need < end) end = need;
+    }
     int main_lo = (32 + MACRO - 1) / MACRO * MACRO;
     if (main_lo > end) main_lo = end;
     int main_hi = (bs_min < bs_max ? bs_min : bs_max) / MACRO * MACRO;
+    if (main_hi > end) main_hi = end;
     if (main_hi < main_lo) main_hi = main_lo;
     for (int pass = 0; pass < 2; ++pass) {
         const int g_lo = pass == 0 ? 0 : main_hi;

@@ -58,6 +58,9 @@ constexpr int kFCrcXpow = 520;                                  // x^(8 (i - 255
 #ifndef FA_F_WBATCH
 #define FA_F_WBATCH 4  // groups of 4 samples whose window values are in flight together in the lag loops
 #endif
+#ifndef FA_F_CEIL
+#define FA_F_CEIL 0  // experiment (r02s): one instruction per sample fewer, yet slower in the same-box A/B
+#endif
 #ifndef FA_F_WAVES
 #define FA_F_WAVES 3  // waves per SIMD the register allocation aims at
 #endif
@@ -766,11 +769,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const double xd = (double)xs[e];
+#if FA_F_CEIL
+                            // r = x - floor(sum of q x / 2^sh) = ceil(x - sum): the sample seeds the chain (every partial sum is
+                            // an exact multiple of 2^-sh below 2^50, so the order of the terms is free)
+                            double t = xd;
+#pragma unroll
+                            for (int j = 0; j < MLO; ++j) t = __builtin_fma(-qd[j], hx[j], t);
+                            const double r = fa_ceil(t);
+#else
                             double sum = 0.0;
 #pragma unroll
                             for (int j = 0; j < MLO; ++j) sum = __builtin_fma(qd[j], hx[j], sum);
                             const double pred = fa_floor(sum);
                             const double r = xd - pred;
+#endif
                             if constexpr (MASK) {
                                 const bool v = (gi0 + e >= lo);
                                 const double ar = v ? fa_fabs(r) : 0.0;

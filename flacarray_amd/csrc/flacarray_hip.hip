@@ -14,6 +14,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <vector>
 
 #include "../../include/flacarray_hip.h"
@@ -336,13 +337,48 @@ int run_verify(const DecodeArgs& a, int* d_err, int* h_err, hipStream_t st) {
     return FA_ERROR_NONE;
 }
 
+// A decode index: what K6 derives from a store (stream metadata, the byte offset of every frame), kept in device memory
+// of its own so that many reads of one store -- the reference's usage pattern, array.py:409-449 -- do not re-parse
+// 4096 stream headers and rebuild a million-entry frame table per call (fa_decode_index_create).
+struct DecodeIndex {
+    const unsigned char* bytes = nullptr;  // the store (owned by the caller, must outlive the index)
+    int64_t n_bytes = 0, n_stream = 0, stream_size = 0, nf = 0;
+    int32_t B = 0, nch = 1;
+    StreamMeta* meta = nullptr;
+    int64_t* ftab = nullptr;
+    int* err = nullptr;       // 64 ints
+    void* tasks = nullptr;    // task table of the scattered-slice calls (grown on demand)
+    size_t tasks_bytes = 0;
+    int device = -1;
+};
+
+// idx == nullptr: parse + index into the cached scratch, then decode (one-off calls).
+// idx != nullptr, build_only: parse + index into buffers owned by *idx, no decode.
+// idx != nullptr, !build_only: decode with the index (d_bytes / d_starts / d_nbytes are not looked at).
 int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int64_t* d_starts, const int64_t* d_nbytes,
                        int64_t n_stream, int64_t stream_size, int64_t first_decode, int64_t n_decode, int64_t n_slices,
                        const int64_t* slice_stream, const int64_t* slice_first, const int64_t* slice_count,
                        const int64_t* out_offset, int32_t* d_out_i32, float* d_out_f32, const float* d_offsets,
                        const float* d_gains, hipStream_t st, int nch = 1, int64_t* d_out_i64 = nullptr, double* d_out_f64 = nullptr,
-                       const double* d_offsets64 = nullptr, const double* d_gains64 = nullptr) {
+                       const double* d_offsets64 = nullptr, const double* d_gains64 = nullptr, DecodeIndex* idx = nullptr,
+                       bool build_only = false) {
+    int rc = FA_ERROR_NONE;
+    int h_err[4] = {0, 0, 0, 0};
+    StreamMeta* d_meta = nullptr;
+    int64_t* d_ftab = nullptr;
+    int* d_err = nullptr;
+    int32_t B = 0;
+    int64_t nf = 0;
+    const bool use_index = (idx != nullptr) && !build_only;
+    if (use_index) {
+        d_bytes = idx->bytes; n_bytes = idx->n_bytes; n_stream = idx->n_stream; stream_size = idx->stream_size;
+        d_meta = idx->meta; d_ftab = idx->ftab; d_err = idx->err; B = idx->B; nf = idx->nf;
+        if (idx->nch != nch) return FA_ERROR_DECODE_INIT;
+        prof_begin(4, st);
+        FA_HIP_TRY(hipMemsetAsync(d_err, 0, 16, st));
+    } else {
     // the decode kernel issues 16-byte loads relative to the blob base: realign if necessary
+    if (build_only && (reinterpret_cast<uintptr_t>(d_bytes) & 15)) return FA_ERROR_DECODE_INIT;  // (an index refers to the caller's bytes)
     if (reinterpret_cast<uintptr_t>(d_bytes) & 15) {
         void* al = nullptr;
         int rc0 = get_scratch(7, (size_t)n_bytes + 256, &al);
@@ -354,32 +390,41 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
     prof_begin(4, st);
     void* p = nullptr;
     const size_t meta_bytes = align_up((size_t)n_stream * sizeof(StreamMeta), 256);
-    int rc = get_scratch(1, meta_bytes + 256 + (size_t)n_stream * 4, &p);
-    if (rc) return rc;
-    StreamMeta* d_meta = reinterpret_cast<StreamMeta*>(p);
+    if (build_only) {
+        FA_HIP_TRY(hipMalloc(&p, meta_bytes + 256 + (size_t)n_stream * 4));
+        idx->meta = reinterpret_cast<StreamMeta*>(p);  // (fa_decode_index_destroy frees what is set, also after an error)
+    } else {
+        rc = get_scratch(1, meta_bytes + 256 + (size_t)n_stream * 4, &p);
+        if (rc) return rc;
+    }
+    d_meta = reinterpret_cast<StreamMeta*>(p);
     // [0]=err [1]=variant flags [2]=streams without a seek table [3]=scan passes of the longest of them
-    int* d_err = reinterpret_cast<int*>(reinterpret_cast<char*>(p) + meta_bytes);
+    d_err = reinterpret_cast<int*>(reinterpret_cast<char*>(p) + meta_bytes);
     int* d_sflag = d_err + 64;  // per stream: 1 = sync scan ambiguous, walk serially
     FA_HIP_TRY(hipMemsetAsync(d_err, 0, 16, st));
     hipLaunchKernelGGL(parse_streams_kernel, dim3((unsigned)((n_stream + 255) / 256)), dim3(256), 0, st, d_bytes, d_starts,
                        d_nbytes, n_stream, stream_size, n_bytes, d_meta, d_err);
     StreamMeta m0;
-    int h_err[4] = {0, 0, 0, 0};
     FA_HIP_TRY(hipMemcpyAsync(&m0, d_meta, sizeof(StreamMeta), hipMemcpyDeviceToHost, st));
     FA_HIP_TRY(hipMemcpyAsync(h_err, d_err, 16, hipMemcpyDeviceToHost, st));
     FA_HIP_TRY(hipStreamSynchronize(st));
     if (h_err[0]) return h_err[0];
-    const int32_t B = m0.B;
+    B = m0.B;
     if (m0.channels != nch) return FA_ERROR_DECODE_INIT;  // an int32 stream read as int64 or the reverse
     if (B <= 0 || B > 65535) return FA_ERROR_DECODE_INIT;
     if (B > kMaxBlock * 16) return FA_ERROR_DECODE_INIT;
-    const int64_t nf = (stream_size + B - 1) / B;
+    nf = (stream_size + B - 1) / B;
 
     // ---- frame table ----
     void* pt = nullptr;
-    rc = get_scratch(2, (size_t)n_stream * (size_t)nf * 8 + 256, &pt);
-    if (rc) return rc;
-    int64_t* d_ftab = reinterpret_cast<int64_t*>(pt);
+    if (build_only) {
+        FA_HIP_TRY(hipMalloc(&pt, (size_t)n_stream * (size_t)nf * 8 + 256));
+        idx->ftab = reinterpret_cast<int64_t*>(pt);
+    } else {
+        rc = get_scratch(2, (size_t)n_stream * (size_t)nf * 8 + 256, &pt);
+        if (rc) return rc;
+    }
+    d_ftab = reinterpret_cast<int64_t*>(pt);
     const int64_t nt = n_stream * nf;
     hipLaunchKernelGGL(build_frame_table_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, d_bytes, d_meta, n_stream,
                        nf, B, nch, d_ftab, d_err);
@@ -396,6 +441,16 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
         hipLaunchKernelGGL(walk_frames_kernel, dim3((unsigned)((n_stream + 63) / 64)), dim3(64), 0, st, d_bytes, n_bytes, d_meta,
                            n_stream, nf, B, stream_size, d_ftab, scan ? d_sflag : (const int*)nullptr, d_err);
     }
+    if (build_only) {
+        FA_HIP_TRY(hipMemcpyAsync(h_err, d_err, 16, hipMemcpyDeviceToHost, st));
+        FA_HIP_TRY(hipStreamSynchronize(st));
+        FA_HIP_TRY(hipGetLastError());
+        if (h_err[0]) return h_err[0];
+        idx->bytes = d_bytes; idx->n_bytes = n_bytes; idx->n_stream = n_stream; idx->stream_size = stream_size; idx->nf = nf;
+        idx->B = B; idx->nch = nch; idx->err = d_err;
+        return FA_ERROR_NONE;
+    }
+    }  // (!use_index)
 
     // ---- K7 ----
     DecodeArgs a;
@@ -412,28 +467,41 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
         a.n_tasks = n_stream * a.nfr;
     } else {
         // scattered slices: one task per (slice, frame)
-        std::vector<int64_t> ts, tf, t0, t1, to;
+        int64_t n_tasks = 0;
         for (int64_t i = 0; i < n_slices; ++i) {
             const int64_t s = slice_stream[i], fst = slice_first[i], cnt = slice_count[i];
             if (s < 0 || s >= n_stream || fst < 0 || cnt <= 0 || fst + cnt > stream_size) return FA_ERROR_DECODE_SAMPLE_RANGE;
-            for (int64_t f = fst / B; f <= (fst + cnt - 1) / B; ++f) {
-                ts.push_back(s); tf.push_back(f); t0.push_back(fst); t1.push_back(fst + cnt); to.push_back(out_offset[i]);
+            n_tasks += (fst + cnt - 1) / B - fst / B + 1;
+        }
+        a.n_tasks = n_tasks;
+        if (a.n_tasks == 0) return FA_ERROR_NONE;
+        // one staging vector, one copy: [stream | frame | first | last | out offset], each n_tasks long
+        const size_t stp = align_up((size_t)n_tasks * 8, 256);
+        std::vector<int64_t> h(5 * stp / 8);
+        int64_t t = 0;
+        for (int64_t i = 0; i < n_slices; ++i) {
+            const int64_t s = slice_stream[i], fst = slice_first[i], cnt = slice_count[i];
+            for (int64_t f = fst / B; f <= (fst + cnt - 1) / B; ++f, ++t) {
+                h[0 * stp / 8 + t] = s; h[1 * stp / 8 + t] = f; h[2 * stp / 8 + t] = fst; h[3 * stp / 8 + t] = fst + cnt;
+                h[4 * stp / 8 + t] = out_offset[i];
             }
         }
-        a.n_tasks = (int64_t)ts.size();
-        if (a.n_tasks == 0) return FA_ERROR_NONE;
         void* pl = nullptr;
-        const size_t nb = (size_t)a.n_tasks * 8;
-        rc = get_scratch(3, 5 * align_up(nb, 256), &pl);
-        if (rc) return rc;
+        if (use_index) {
+            if (idx->tasks_bytes < 5 * stp) {
+                if (idx->tasks) (void)hipFree(idx->tasks);
+                idx->tasks = nullptr; idx->tasks_bytes = 0;
+                FA_HIP_TRY(hipMalloc(&idx->tasks, 5 * stp + 4096));
+                idx->tasks_bytes = 5 * stp + 4096;
+            }
+            pl = idx->tasks;
+        } else {
+            rc = get_scratch(3, 5 * stp, &pl);
+            if (rc) return rc;
+        }
         char* c = reinterpret_cast<char*>(pl);
-        const size_t stp = align_up(nb, 256);
-        FA_HIP_TRY(hipMemcpyAsync(c + 0 * stp, ts.data(), nb, hipMemcpyHostToDevice, st));
-        FA_HIP_TRY(hipMemcpyAsync(c + 1 * stp, tf.data(), nb, hipMemcpyHostToDevice, st));
-        FA_HIP_TRY(hipMemcpyAsync(c + 2 * stp, t0.data(), nb, hipMemcpyHostToDevice, st));
-        FA_HIP_TRY(hipMemcpyAsync(c + 3 * stp, t1.data(), nb, hipMemcpyHostToDevice, st));
-        FA_HIP_TRY(hipMemcpyAsync(c + 4 * stp, to.data(), nb, hipMemcpyHostToDevice, st));
-        FA_HIP_TRY(hipStreamSynchronize(st));  // the host vectors go out of scope
+        FA_HIP_TRY(hipMemcpyAsync(c, h.data(), 5 * stp, hipMemcpyHostToDevice, st));
+        FA_HIP_TRY(hipStreamSynchronize(st));  // the host vector goes out of scope
         a.task_stream = reinterpret_cast<const int64_t*>(c + 0 * stp);
         a.task_frame = reinterpret_cast<const int64_t*>(c + 1 * stp);
         a.task_first = reinterpret_cast<const int64_t*>(c + 2 * stp);
@@ -959,6 +1027,67 @@ int fa_decode_slices_i32_device(const unsigned char* d_bytes, int64_t n_bytes, c
     return decode_device_impl(d_bytes, n_bytes, d_starts, d_nbytes, n_stream, stream_size, 0, 0, n_slices, slice_stream,
                               slice_first, slice_count, out_offset, d_out_i32, d_out_f32, d_offsets, d_gains,
                               reinterpret_cast<hipStream_t>(stream));
+}
+
+int fa_decode_index_create(const unsigned char* d_bytes, int64_t n_bytes, const int64_t* d_starts, const int64_t* d_nbytes,
+                           int64_t n_stream, int64_t stream_size, int channels, void** index, void* stream) {
+    FA_API_LOCK;
+    if (!index) return FA_ERROR_ALLOC;
+    *index = nullptr;
+    if (n_stream <= 0) return FA_ERROR_ZERO_NSTREAM;
+    if (stream_size <= 0) return FA_ERROR_DECODE_STREAMSIZE;
+    if (channels != 1 && channels != 2) return FA_ERROR_CONVERT_TYPE;
+    DecodeIndex* ix = new (std::nothrow) DecodeIndex();
+    if (!ix) return FA_ERROR_ALLOC;
+    (void)hipGetDevice(&ix->device);
+    const int rc = decode_device_impl(d_bytes, n_bytes, d_starts, d_nbytes, n_stream, stream_size, 0, 0, -1, nullptr, nullptr, nullptr, nullptr,
+                                      nullptr, nullptr, nullptr, nullptr, reinterpret_cast<hipStream_t>(stream), channels, nullptr, nullptr,
+                                      nullptr, nullptr, ix, true);
+    if (rc) {
+        if (ix->meta) (void)hipFree(ix->meta);
+        if (ix->ftab) (void)hipFree(ix->ftab);
+        delete ix;
+        return rc;
+    }
+    *index = ix;
+    return FA_ERROR_NONE;
+}
+
+void fa_decode_index_destroy(void* index) {
+    DecodeIndex* ix = reinterpret_cast<DecodeIndex*>(index);
+    if (!ix) return;
+    FA_API_LOCK_OR(return);
+    if (ix->meta) (void)hipFree(ix->meta);
+    if (ix->ftab) (void)hipFree(ix->ftab);
+    if (ix->tasks) (void)hipFree(ix->tasks);
+    delete ix;
+}
+
+int fa_decode_indexed(void* index, int64_t first_sample, int64_t last_sample, int64_t n_slices, const int64_t* slice_stream,
+                      const int64_t* slice_first, const int64_t* slice_count, const int64_t* out_offset, void* d_out_int,
+                      void* d_out_float, const void* d_offsets, const void* d_gains, void* stream) {
+    FA_API_LOCK;
+    DecodeIndex* ix = reinterpret_cast<DecodeIndex*>(index);
+    if (!ix) return FA_ERROR_DECODE_INIT;
+    if ((d_out_int == nullptr) == (d_out_float == nullptr)) return FA_ERROR_CONVERT_TYPE;
+    if (d_out_float && (!d_offsets || !d_gains)) return FA_ERROR_CONVERT_TYPE;
+    int64_t first_decode = 0, n_decode = 0;
+    if (n_slices < 0) {
+        const int rc = validate_range(ix->stream_size, first_sample, last_sample, &first_decode, &n_decode);
+        if (rc) return rc;
+    } else if (n_slices == 0) {
+        return FA_ERROR_NONE;
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (ix->nch == 1)
+        return decode_device_impl(nullptr, 0, nullptr, nullptr, 0, 0, first_decode, n_decode, n_slices, slice_stream, slice_first, slice_count,
+                                  out_offset, reinterpret_cast<int32_t*>(d_out_int), reinterpret_cast<float*>(d_out_float),
+                                  reinterpret_cast<const float*>(d_offsets), reinterpret_cast<const float*>(d_gains), st, 1, nullptr, nullptr,
+                                  nullptr, nullptr, ix, false);
+    return decode_device_impl(nullptr, 0, nullptr, nullptr, 0, 0, first_decode, n_decode, n_slices, slice_stream, slice_first, slice_count,
+                              out_offset, nullptr, nullptr, nullptr, nullptr, st, 2, reinterpret_cast<int64_t*>(d_out_int),
+                              reinterpret_cast<double*>(d_out_float), reinterpret_cast<const double*>(d_offsets),
+                              reinterpret_cast<const double*>(d_gains), ix, false);
 }
 
 int fa_decode_i64_device(const unsigned char* d_bytes, int64_t n_bytes, const int64_t* d_starts,

@@ -490,6 +490,100 @@ def decode_slices_device(compressed, starts, nbytes, stream_size, slice_stream, 
     return out, out_off
 
 
+class DeviceDecodeIndex:
+    """Decode index of one HBM-resident store (fa_decode_index_create): the stream headers are parsed and the byte
+    offset of every frame is tabulated ONCE; `decode` / `decode_slices` then cost one kernel launch each.  Holds
+    references to the store's tensors (the C side refers to their memory)."""
+
+    def __init__(self, compressed, starts, nbytes, stream_size, is_int64=False):
+        torch = _torch()
+        if compressed.dtype != torch.uint8 or starts.dtype != torch.int64 or nbytes.dtype != torch.int64:
+            raise RuntimeError("Compressed data should be of type uint8")
+        self.compressed = compressed.contiguous()
+        self.starts = starts.reshape(-1).contiguous()
+        self.nbytes = nbytes.reshape(-1).contiguous()
+        self.stream_size = int(stream_size)
+        self.n_stream = int(self.starts.numel())
+        self.is_int64 = bool(is_int64)
+        self.device = compressed.device
+        self._L = _lib.lib()
+        h = ctypes.c_void_p(None)
+        with torch.cuda.device(self.device):
+            errcode = self._L.fa_decode_index_create(
+                _dp(self.compressed), self.compressed.numel(), _dp(self.starts), _dp(self.nbytes), self.n_stream, self.stream_size,
+                2 if is_int64 else 1, ctypes.byref(h), _stream_ptr(),
+            )
+        if errcode != 0:
+            raise RuntimeError(f"Decoding failed, return code = {errcode}")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.fa_decode_index_destroy(self._h)
+            self._h = ctypes.c_void_p(None)
+
+    __del__ = close
+
+    def _types(self, to_float):
+        torch = _torch()
+        ft, it = (torch.float64, torch.int64) if self.is_int64 else (torch.float32, torch.int32)
+        return ft if to_float else it, ft
+
+    def decode(self, first_sample=-1, last_sample=-1, offsets=None, gains=None):
+        """[first_sample, last_sample) (or everything) of ALL streams -> tensor [n_stream, n_decode]."""
+        torch = _torch()
+        n_decode = self.stream_size
+        if first_sample >= 0 and last_sample >= 0:
+            if last_sample > self.stream_size:
+                raise RuntimeError("last_sample is beyond end of stream")
+            if first_sample > self.stream_size - 1:
+                raise RuntimeError("first_sample is beyond last element of stream")
+            if first_sample >= last_sample:
+                raise RuntimeError("first_sample is larger than last_sample")
+            n_decode = last_sample - first_sample
+        dt, ft = self._types(offsets is not None)
+        out = torch.empty((self.n_stream, n_decode), dtype=dt, device=self.device)
+        if offsets is not None:
+            offsets = offsets.reshape(-1).to(device=self.device, dtype=ft).contiguous()
+            gains = gains.reshape(-1).to(device=self.device, dtype=ft).contiguous()
+        with torch.cuda.device(self.device):
+            errcode = self._L.fa_decode_indexed(
+                self._h, first_sample, last_sample, -1, None, None, None, None, None if offsets is not None else _dp(out),
+                _dp(out) if offsets is not None else None, _dp(offsets), _dp(gains), _stream_ptr(),
+            )
+        if errcode != 0:
+            raise RuntimeError(f"Decoding failed, return code = {errcode}")
+        return out
+
+    def decode_slices(self, slice_stream, slice_first, slice_count, offsets=None, gains=None):
+        """Batched random access (see decode_slices_device): returns (flat tensor, int64 numpy array of offsets)."""
+        torch = _torch()
+        slice_stream = np.ascontiguousarray(slice_stream, dtype=np.int64)
+        slice_first = np.ascontiguousarray(slice_first, dtype=np.int64)
+        slice_count = np.ascontiguousarray(slice_count, dtype=np.int64)
+        n = slice_stream.shape[0]
+        out_off = np.zeros(n, dtype=np.int64)
+        if n > 1:
+            np.cumsum(slice_count[:-1], out=out_off[1:])
+        dt, ft = self._types(offsets is not None)
+        out = torch.empty(int(slice_count.sum()), dtype=dt, device=self.device)
+        if n == 0:
+            return out, out_off
+        if offsets is not None:
+            offsets = offsets.reshape(-1).to(device=self.device, dtype=ft).contiguous()
+            gains = gains.reshape(-1).to(device=self.device, dtype=ft).contiguous()
+        with torch.cuda.device(self.device):
+            errcode = self._L.fa_decode_indexed(
+                self._h, -1, -1, n, ctypes.c_void_p(slice_stream.ctypes.data), ctypes.c_void_p(slice_first.ctypes.data),
+                ctypes.c_void_p(slice_count.ctypes.data), ctypes.c_void_p(out_off.ctypes.data),
+                None if offsets is not None else _dp(out), _dp(out) if offsets is not None else None, _dp(offsets), _dp(gains),
+                _stream_ptr(),
+            )
+        if errcode != 0:
+            raise RuntimeError(f"Decoding failed, return code = {errcode}")
+        return out, out_off
+
+
 def float32_to_int32_device(data, quanta=None):
     """Device float32 -> int32 quantisation (utils.c:160-243); returns (int32 tensor, offsets, gains)."""
     torch = _torch()

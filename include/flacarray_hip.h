@@ -157,6 +157,20 @@ int fa_decode_i64_device(const unsigned char* d_bytes, int64_t n_bytes, const in
                          int64_t last_sample, int64_t* d_out_i64, double* d_out_f64, const double* d_offsets,
                          const double* d_gains, void* stream);
 
+/* A decode index: the stream metadata and the byte offset of every frame of one store, computed once (K6) and kept in
+ * device memory, for many reads of the same store -- the reference's usage pattern is one decode call per key
+ * (array.py:409-449), and without an index every call parses every stream header again.  The store (d_bytes, 16-byte
+ * aligned) must stay alive and unchanged while the index exists; channels = 1 (int32 / float32) or 2 (int64 / float64).
+ * fa_decode_indexed: n_slices < 0 decodes [first_sample, last_sample) (or everything) of ALL streams, as
+ * fa_decode_i32_device does; n_slices >= 0 is the batched random access of fa_decode_slices_i32_device.  d_out_int /
+ * d_out_float are int32 / float32 for one channel, int64 / float64 for two (offsets / gains likewise). */
+int fa_decode_index_create(const unsigned char* d_bytes, int64_t n_bytes, const int64_t* d_starts, const int64_t* d_nbytes,
+                           int64_t n_stream, int64_t stream_size, int channels, void** index, void* stream);
+void fa_decode_index_destroy(void* index);
+int fa_decode_indexed(void* index, int64_t first_sample, int64_t last_sample, int64_t n_slices, const int64_t* slice_stream,
+                      const int64_t* slice_first, const int64_t* slice_count, const int64_t* out_offset, void* d_out_int,
+                      void* d_out_float, const void* d_offsets, const void* d_gains, void* stream);
+
 /* Integrity check of the decoder (process-wide switch, returns the previous setting; default off).  When on, every
  * decode call re-computes the CRC-16 of each frame it read and reports a mismatch as FA_ERROR_DECODE_PROCESS -- what
  * libFLAC reports through the error callback the reference prints (decompress.c:104-121).  The header CRC-8 of every

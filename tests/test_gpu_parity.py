@@ -489,6 +489,65 @@ def test_resident_flacarray(fa):
     assert np.array_equal(r2[5, 100:300], x.reshape(24, -1)[5, 100:300])
 
 
+@pytest.mark.parametrize("kind", ["i32", "f32", "i64", "noseek"])
+def test_decode_index_matches_plain_decode(fa, oracle, kind):
+    """fa_decode_index_create / fa_decode_indexed: the index (headers parsed, frame offsets tabulated once) must
+    answer whole decodes, sample ranges and slice batches exactly like the one-shot entry points, any number of
+    times, and reject what they reject."""
+    import torch
+
+    from tests.conftest import strip_seektable
+
+    n = 30011
+    dev = torch.device("cuda", 0)
+    off = gain = None
+    if kind == "i64":
+        rng = np.random.default_rng(3)
+        x = (rng.integers(-(2**40), 2**40, (5, n)) + np.cumsum(rng.integers(-900, 900, (5, n)), axis=1)).astype(np.int64)
+        blob, st, nb = fa.encode_flac(x, 5)
+    else:
+        x = np.concatenate([sinusoid_noise_i32(9, n, seed=15), full_range_i32((2, n), seed=16)])
+        blob, st, nb = oracle.encode_i32(x, 5)
+        if kind == "noseek":
+            blob, st, nb = strip_seektable(blob, st, nb)
+        if kind == "f32":
+            off = torch.linspace(-3, 3, x.shape[0])
+            gain = torch.linspace(1e-3, 2e-3, x.shape[0])
+    tb, ts, tn = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (blob, st, nb))
+    idx = fa.DeviceDecodeIndex(tb, ts, tn, n, is_int64=(kind == "i64"))
+    plain = lambda f, l: fa.decode_flac_device(tb, ts, tn, n, f, l, offsets=off, gains=gain, is_int64=(kind == "i64"))  # noqa: E731
+    for rep in range(2):
+        for f, l in ((-1, -1), (0, n), (5, 6), (4095, 4097), (n - 1, n), (12345, 29000)):
+            assert torch.equal(idx.decode(f, l, offsets=off, gains=gain), plain(f, l)), (rep, f, l)
+        rng = np.random.default_rng(77 + rep)
+        ss = rng.integers(0, x.shape[0], 300)
+        cnt = rng.integers(1, 9000, 300)
+        first = np.array([rng.integers(0, n - c + 1) for c in cnt])
+        a, ao = idx.decode_slices(ss, first, cnt, offsets=off, gains=gain)
+        b, bo = fa.decode_slices_device(tb, ts, tn, n, ss, first, cnt, offsets=off, gains=gain, is_int64=(kind == "i64"))
+        assert np.array_equal(ao, bo) and torch.equal(a, b)
+        if off is None:
+            flat = a.cpu().numpy()
+            for o, s_i, f0, c in zip(ao, ss, first, cnt):
+                assert np.array_equal(flat[o : o + c], x[s_i, f0 : f0 + c])
+    with pytest.raises(RuntimeError):
+        idx.decode(10, n + 1)
+    with pytest.raises(RuntimeError, match="Decoding failed"):
+        idx.decode_slices(np.array([0, x.shape[0]]), np.array([0, 0]), np.array([5, 5]))
+    with pytest.raises(RuntimeError, match="Decoding failed"):
+        idx.decode_slices(np.array([0]), np.array([n - 3]), np.array([5]))
+    assert torch.equal(idx.decode(offsets=off, gains=gain), plain(-1, -1))  # still usable after rejected calls
+    idx.close()
+    idx.close()
+    # a damaged store is rejected when the index is built
+    bad = tb.clone()
+    bad[int(st[1]) : int(st[1]) + 4] = 0
+    with pytest.raises(RuntimeError, match="Decoding failed"):
+        fa.DeviceDecodeIndex(bad, ts, tn, n, is_int64=(kind == "i64"))
+    with pytest.raises(RuntimeError, match="Decoding failed"):
+        fa.DeviceDecodeIndex(tb, ts + 10**12, tn, n, is_int64=(kind == "i64"))
+
+
 @pytest.mark.parametrize("level,n", [(5, 100000), (0, 50001), (8, 4096 * 3)])
 def test_decode_without_seektable(fa, oracle, level, n):
     """Streams without a SEEKTABLE (what libFLAC writes through the reference, compress.c:337-390)
