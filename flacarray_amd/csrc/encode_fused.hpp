@@ -1016,6 +1016,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
         atomicOr(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ring) + a0), (uint32_t)(X >> 32));
         atomicOr(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ring) + a0 + 4), (uint32_t)X);  // may be the mirror word
     };
+    // One Rice code whose stop bit lands at stream bit P: the stop bit and the k low bits of u, left-aligned in a word
+    // (shl = 31 - k; whatever u holds above bit k is shifted out or falls on the stop bit), then funnel-shifted to
+    // P mod 32 -- v_alignbit takes the shift modulo 32, so there is no mask, no 64-bit shift and no subtraction.
+    auto put_code = [&](uint32_t P, uint32_t u, uint32_t shl) __attribute__((always_inline)) {
+        const uint32_t vL = (u << shl) | 0x80000000u;
+        uint32_t wi;  // (asm: the compiler rewrites the bit-field extract into shift + mask and then needs a separate add)
+        asm("v_bfe_u32 %0, %1, 5, %2" : "=v"(wi) : "v"(P), "n"(__builtin_ctz((unsigned)kFRingWords)));
+        uint32_t* const w = ring + wi;
+        atomicOr(w, __builtin_amdgcn_alignbit(0u, vL, P));
+        atomicOr(w + 1, __builtin_amdgcn_alignbit(vL, 0u, P));  // may be the mirror word
+    };
     // byte offset of the frame: the scanner stores it in off_pub[g] once every frame before it has published.
     // lb_issue reads the word once (usually still zero); lb_resolve, where the first block is about to leave the
     // ring, polls it until it is there.
@@ -1041,7 +1052,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
         st_[3] += spins;                 // polls
         st_[14] += (spins == 0) ? 1 : 0;  // frames whose offset was there when they asked
 #endif
-        const int64_t off = (int64_t)off_word;
+        // (every lane loaded the same word: say so, the destination then lives in scalar registers)
+        const int64_t off = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(off_word >> 32)) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off_word));
+        fail = __builtin_amdgcn_readfirstlane((int)fail) != 0;
         if (fail || off < 0 || off + (int64_t)total_bytes > a.capacity) {
             if (lane == 0) atomicOr(a.err, fail ? 2 : 1);
             dropped = true;  // the frame is not written; the host reports the error
@@ -1082,6 +1096,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
             }
         }
     };
+    // A complete 256-byte block behind the frame's first lies inside [0, total_bytes) whatever the alignment: its 64
+    // aligned dwords need no range tests (emit_word's byte-wise path serves the frame's first and last dwords only).
+    auto emit_block = [&](uint32_t blk, uint32_t Q) __attribute__((always_inline)) {
+        const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u);
+        const uint32_t P = (uint32_t)dpp_wave_shr1((int)carry, (int)Q);
+        carry = (uint32_t)__builtin_amdgcn_readlane((int)Q, 63);
+        const uint32_t V = __builtin_amdgcn_alignbit(P, Q, 8u * sh);
+        *reinterpret_cast<uint32_t*>(dst - sh + 256u * blk + 4u * (uint32_t)lane) = __builtin_bswap32(V);
+    };
     auto flush_blocks = [&]() __attribute__((always_inline)) {
         const uint32_t done = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pos >> 11));
         blocks_flushed = (uint32_t)__builtin_amdgcn_readfirstlane((int)blocks_flushed);
@@ -1091,9 +1114,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
             const uint32_t wi = (blocks_flushed * 64 + lane) & kFRingMask;
             uint32_t wv = ring[wi];
             ring[wi] = 0;
-            if ((blocks_flushed & (uint32_t)(kFRingBlocks - 1)) == 0 && lane == 0) { wv |= ring[kFRingWords]; ring[kFRingWords] = 0; }
+            if (__builtin_expect((blocks_flushed & (uint32_t)(kFRingBlocks - 1)) == 0, 0)) {
+                if (lane == 0) { wv |= ring[kFRingWords]; ring[kFRingWords] = 0; }
+            }
             crc_word(wv);
-            if (!dropped) emit_word(blocks_flushed * 64 + (uint32_t)lane, wv);
+            if (!dropped) {
+                if (__builtin_expect(blocks_flushed == 0, 0)) emit_word((uint32_t)lane, wv);
+                else emit_block(blocks_flushed, wv);
+            }
             blocks_flushed++;
         }
     };
@@ -1282,7 +1310,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
                             p += q[e] + kp1;
                         }
                     } else {
-                        put_bits(p + q[e], onek | (us[e] & mask), kp1);
+                        put_code(p + q[e], us[e], 31u - k);
                         p += q[e] + kp1;
                     }
                 }
