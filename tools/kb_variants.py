@@ -9,8 +9,12 @@ import sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 args = sys.argv[1:]
 channels = "2048"
-if args and args[0] == "--channels":
-    channels = args[1]
+reps = "15"
+while args and args[0] in ("--channels", "--reps"):
+    if args[0] == "--channels":
+        channels = args[1]
+    else:
+        reps = args[1]
     args = args[2:]
 for rnd in range(2):
     for spec in args:
@@ -22,4 +26,4 @@ for rnd in range(2):
             k, _, v = kv.partition("=")
             env[k] = v
         print(f"--- {spec}", flush=True)
-        subprocess.run([sys.executable, os.path.join(root, "tools", "kbench.py"), "--channels", channels], env=env, check=False)
+        subprocess.run([sys.executable, os.path.join(root, "tools", "kbench.py"), "--channels", channels, "--reps", reps], env=env, check=False)

@@ -48,9 +48,10 @@ def main():
     res = np.array(res)
     n = x.numel()
     c = comp.numel() / n
-    enc, cmp_, dec = res.mean(0)
+    enc, cmp_, dec = np.median(res, axis=0)
     print(f"lib={os.path.basename(_lib.LIB_PATH)} ch={args.channels} c={c:.4f} B/sample")
-    print(f"encode_frames {enc:8.3f} ms  {(4+c)*n/enc/1e6:8.1f} GB/s   compact {cmp_:7.3f} ms   decode_frames {dec:8.3f} ms  {(4+c)*n/dec/1e6:8.1f} GB/s")
+    print(f"encode_frames {enc:8.3f} ms  {(4+c)*n/enc/1e6:8.1f} GB/s   compact {cmp_:7.3f} ms   decode_frames {dec:8.3f} ms  {(4+c)*n/dec/1e6:8.1f} GB/s"
+          f"   (median of {len(res)}; encode min {res[:, 0].min():.3f} max {res[:, 0].max():.3f})")
     if hasattr(L, "fa_debug_stamps"):
         buf = (ctypes.c_ulonglong * 32)()
         L.fa_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
