@@ -33,6 +33,9 @@
 namespace fa {
 
 constexpr int kFSmpWords = 65 * 32;  // zero history chunk + 64 chunks of the first half
+#ifndef FA_F_SCANW
+#define FA_F_SCANW 4  // size words per lane and scanner step (x 64 = entries per step)
+#endif
 #ifndef FA_F_RING
 #define FA_F_RING 1024  // words of the bit ring (power of two >= 512)
 #endif
@@ -245,16 +248,16 @@ __device__ __forceinline__ void fused_scanner(const FusedArgs& a, int lane) {
     uint64_t prefix = 0;
     uint32_t idle = 0;
     while (pos < F) {
-        uint32_t v[4];
+        uint32_t v[FA_F_SCANW];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < FA_F_SCANW; ++k) {
             const uint32_t i = pos + 64u * k + (uint32_t)lane;
             v[k] = (i < F) ? lb_load(a.size_pub + i) : 0u;
         }
         uint32_t adv = 0;
         bool open = true;  // no gap so far
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < FA_F_SCANW; ++k) {
             const uint64_t ball = __ballot((v[k] >> 31) != 0);
             const uint32_t cnt = open ? ((ball == ~0ULL) ? 64u : (uint32_t)__builtin_ctzll(~ball)) : 0u;
             if (cnt > 0) {
@@ -264,6 +267,9 @@ __device__ __forceinline__ void fused_scanner(const FusedArgs& a, int lane) {
                 if ((uint32_t)lane < cnt) {
                     const uint64_t off = prefix + (incl - mine) + (uint64_t)(i / nf + 1u) * (uint64_t)a.hb;
                     __hip_atomic_store(a.off_pub + i, (unsigned long long)off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef FA_TIMELINE
+                    if (a.info) a.info[i].porder = (int32_t)(uint32_t)__builtin_amdgcn_s_memrealtime();  // offset out
+#endif
                 }
                 prefix += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                 adv += cnt;
@@ -348,6 +354,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
     constexpr int tailA7 = 32 * 64 + 4 * (7 ^ (64 & 7)), tailA6 = 32 * 64 + 4 * (6 ^ (64 & 7)), tailA5 = 32 * 64 + 4 * (5 ^ (64 & 7));
 
     FA_STAMP_INIT;
+#ifdef FA_TIMELINE
+    const uint32_t tl_start_ = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
     // ---- P0: stage the frame, wasted bits, constant / narrow tests -----------------------------------
     int4 Bv[8];  // B_l: samples 2048 + 32 l + 4 t + {0,1,2,3}
     uint32_t orv = 0;
@@ -980,11 +989,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
     // ---- publish the size ------------------------------------------------------------------------------
     const uint32_t F = (uint32_t)a.total_frames;
     const uint32_t gu = (uint32_t)g;
+#ifdef FA_TIMELINE
+    // diagnostic build: the optional FrameInfo record carries 100 MHz timestamps instead of the decisions
+    // (wasted = start, shift = size published, porder = offset out (written by the scanner), precision = offset asked
+    // for, blocksize = offset seen)
+    if (lane == 0 && a.info) {
+        a.info[g].wasted = (int32_t)tl_start_;
+        a.info[g].shift = (int32_t)(uint32_t)__builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0);
+    }
+#endif
     if (lane == 0) {
         __hip_atomic_store(a.size_pub + gu, 0x80000000u | total_bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         a.frame_bytes[g] = total_bytes;
     }
     (void)F;
+#ifndef FA_TIMELINE
     if (lane == 0 && a.info) {
         FrameInfo fi;
         fi.type = type;
@@ -997,6 +1017,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
         fi.blocksize = bs;
         a.info[g] = fi;
     }
+#endif
 
     // ---- writer state ------------------------------------------------------------------------------------
     kpar[lane] = (uint8_t)kbest;
@@ -1039,6 +1060,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
     auto lb_resolve = [&]() __attribute__((always_inline)) {
         uint32_t spins = 0;
         bool fail = false;
+#ifdef FA_TIMELINE
+        const uint32_t tl_req_ = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef FA_F_NOLB  // timing experiment only (frames land at slot positions): what the wait costs
         off_word = (unsigned long long)(g * (int64_t)kSlotBytes + (s + 1) * a.hb);
 #else
@@ -1048,9 +1072,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
             off_word = lb_load(a.off_pub + gu);
         }
 #endif
+#ifdef FA_TIMELINE
+        if (lane == 0 && a.info) {
+            a.info[g].precision = (int32_t)tl_req_;
+            a.info[g].blocksize = (int32_t)(uint32_t)__builtin_amdgcn_s_memrealtime();
+        }
+#endif
 #ifdef FA_STAMPS
         st_[3] += spins;                 // polls
-        st_[14] += (spins == 0) ? 1 : 0;  // frames whose offset was there when they asked
 #endif
         // (every lane loaded the same word: say so, the destination then lives in scalar registers)
         const int64_t off = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(off_word >> 32)) << 32) |
@@ -1109,7 +1138,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
         const uint32_t done = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pos >> 11));
         blocks_flushed = (uint32_t)__builtin_amdgcn_readfirstlane((int)blocks_flushed);
         if (done - blocks_flushed < (uint32_t)kFFlushHold) return;
+#ifdef FA_STAMPS
+        const unsigned long long tq0_ = fa_memtime();
+#endif
         if (!have_dst) lb_resolve();
+#ifdef FA_STAMPS
+        st_[14] += fa_memtime() - tq0_;  // (part of the flush calls: waiting for the frame's offset)
+#endif
         while (blocks_flushed < done) {
             const uint32_t wi = (blocks_flushed * 64 + lane) & kFRingMask;
             uint32_t wv = ring[wi];
@@ -1318,7 +1353,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
                     if (newp) put_bits(p0, k, (uint32_t)plen);
                 }
                 pos += total;
+#ifdef FA_STAMPS
+                const unsigned long long tf0_ = fa_memtime();
+#endif
                 flush_blocks();
+#ifdef FA_STAMPS
+                st_[15] += fa_memtime() - tf0_;  // (part of "rows": the flush calls)
+#endif
             };
             row8(std::true_type{}, 0);
 #pragma unroll 1
@@ -1405,6 +1446,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
         }
     }
     FA_STAMP(12);
+#ifdef FA_STAMPS
+    if (lane == 0 && a.stamps && (blockIdx.x % 61u) == 0) {  // per XCD: frames, offset wait, lifetime (slots 32 + 4 x)
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 7u;
+        unsigned long long life = 0;
+        for (int i_ = 0; i_ < 13; ++i_) life += st_[i_];
+        atomicAdd(&a.stamps[32 + 4 * xcc], 1ULL);
+        atomicAdd(&a.stamps[33 + 4 * xcc], st_[14]);
+        atomicAdd(&a.stamps[34 + 4 * xcc], life);
+        unsigned long long prep = 0;
+        for (int i_ = 0; i_ < 10; ++i_) prep += st_[i_];
+        atomicAdd(&a.stamps[35 + 4 * xcc], prep);  // start -> publish
+    }
+#endif
     FA_STAMP_FLUSH;
 }
 

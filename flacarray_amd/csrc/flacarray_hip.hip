@@ -613,10 +613,10 @@ void fa_profile_enable(int on) { g_prof = (on != 0); }  // process-wide switch; 
 int fa_debug_stamps(unsigned long long* out32, int reset) {
     FA_API_LOCK;
     void* sp = nullptr;
-    if (get_scratch(6, 256, &sp)) return FA_ERROR_DEVICE;
+    if (get_scratch(6, 512, &sp)) return FA_ERROR_DEVICE;
     if (hipDeviceSynchronize() != hipSuccess) return FA_ERROR_DEVICE;
-    if (hipMemcpy(out32, sp, 256, hipMemcpyDeviceToHost) != hipSuccess) return FA_ERROR_DEVICE;
-    if (reset && hipMemset(sp, 0, 256) != hipSuccess) return FA_ERROR_DEVICE;
+    if (hipMemcpy(out32, sp, 512, hipMemcpyDeviceToHost) != hipSuccess) return FA_ERROR_DEVICE;
+    if (reset && hipMemset(sp, 0, 512) != hipSuccess) return FA_ERROR_DEVICE;
     return FA_ERROR_NONE;
 }
 #endif
@@ -712,8 +712,8 @@ static int encode_device_begin(const int32_t* d_data, int nch, int64_t n_stream,
 #ifdef FA_STAMPS
     {
         void* sp = nullptr;
-        if (get_scratch(6, 256, &sp) == 0) {
-            if (!ds_->stamps_zeroed) { (void)hipMemset(sp, 0, 256); ds_->stamps_zeroed = true; }
+        if (get_scratch(6, 512, &sp) == 0) {
+            if (!ds_->stamps_zeroed) { (void)hipMemset(sp, 0, 512); ds_->stamps_zeroed = true; }
             a.stamps = reinterpret_cast<unsigned long long*>(sp);
         }
     }
@@ -897,8 +897,8 @@ static int fused_encode_run(const void* d_data, bool f32, const float* d_quanta,
 #ifdef FA_STAMPS
     {
         void* sp = nullptr;
-        if (get_scratch(6, 256, &sp) == 0) {
-            if (!ds_->stamps_zeroed) { (void)hipMemset(sp, 0, 256); ds_->stamps_zeroed = true; }
+        if (get_scratch(6, 512, &sp) == 0) {
+            if (!ds_->stamps_zeroed) { (void)hipMemset(sp, 0, 512); ds_->stamps_zeroed = true; }
             a.stamps = reinterpret_cast<unsigned long long*>(sp);
         }
     }

@@ -12,8 +12,8 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-PHASES = ["P0 load/wasted", "P2 fixed loop", "P2 reduce", "P2 rice search", "P3 autocorr loop", "P3 butterfly", "P3 levinson+quant",
-          "P4 lpc residual", "P4 rice search", "emit prep", "preamble", "rows", "tail", "(6a) levinson", "(6b) order choice"]
+PHASES = ["P0 load/wasted", "P2 fixed loop", "P2 reduce", "(polls per frame)", "P3 autocorr loop", "P3 butterfly", "P3 levinson+quant",
+          "P4 lpc residual", "P4 rice search", "emit prep", "preamble", "rows", "tail", "tail: offset wait", "(flush: offset wait)"]
 
 
 def main():
@@ -53,7 +53,7 @@ def main():
     print(f"encode_frames {enc:8.3f} ms  {(4+c)*n/enc/1e6:8.1f} GB/s   compact {cmp_:7.3f} ms   decode_frames {dec:8.3f} ms  {(4+c)*n/dec/1e6:8.1f} GB/s"
           f"   (median of {len(res)}; encode min {res[:, 0].min():.3f} max {res[:, 0].max():.3f})")
     if hasattr(L, "fa_debug_stamps"):
-        buf = (ctypes.c_ulonglong * 32)()
+        buf = (ctypes.c_ulonglong * 64)()
         L.fa_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
         L.fa_debug_stamps(buf, 1)
         tot = sum(buf[: len(PHASES)])
@@ -61,6 +61,10 @@ def main():
         print(f"  sampled frames {nfr}, {tot/nfr:.0f} stamped cycles/frame")
         for i, name in enumerate(PHASES):
             print(f"  {name:22s} {buf[i]/max(tot,1)*100:6.2f} %   {buf[i]/nfr:10.0f} cyc/frame")
+        for x in range(8):
+            n_ = max(buf[32 + 4 * x], 1)
+            print(f"  XCD {x}: frames {buf[32 + 4 * x]:6d}  offset wait {buf[33 + 4 * x] / n_:8.0f}  lifetime {buf[34 + 4 * x] / n_:8.0f}  start->publish {buf[35 + 4 * x] / n_:8.0f}")
+        print(f"  (of rows: flush calls   {buf[15]/max(tot,1)*100:6.2f} %   {buf[15]/nfr:10.0f} cyc/frame)")
     if args.check:
         from oracle import oracle as O
 
