@@ -84,13 +84,34 @@ def cpu_baseline(n_samp, seconds_budget=25.0):
     y = O.decode_i32(blob, st, nb, n_samp, use_threads=True)
     t2 = time.perf_counter()
     assert np.array_equal(x, y)
-    return {
+    out = {
         "value": round(x.size / (t2 - t0) / 1e6, 2),
         "unit": "Msamples/s",
         "cores": int(threads),
         "kind": "port",
         "sample": f"{n_ch}ch x {n_samp} int32 sinusoid+noise, level 5, encode {x.size/(t1-t0)/1e6:.1f} + decode {x.size/(t2-t1)/1e6:.1f} Msamples/s",
     }
+    # a system libFLAC, if this box has one, gives the reference's own engine (one thread, through the
+    # ctypes harness of oracle/libflac_harness.py) and a cross-decode of the port's streams
+    try:
+        from oracle import libflac_harness as H
+
+        if H.available():
+            xs = x[:4]
+            t3 = time.perf_counter()
+            lb, ls, ln = H.encode_i32(xs, 5)
+            t4 = time.perf_counter()
+            ys = H.decode_i32(lb, ls, ln, n_samp)
+            t5 = time.perf_counter()
+            cross = bool(np.array_equal(ys, xs)) and bool(np.array_equal(H.decode_i32(blob, st[:4], nb[:4], n_samp), xs))
+            out["libflac"] = {"version": H.version(), "threads": 1, "encode_Msamples_per_s": round(xs.size / (t4 - t3) / 1e6, 2),
+                              "decode_Msamples_per_s": round(xs.size / (t5 - t4) / 1e6, 2), "cross_decode_ok": cross,
+                              "bytes_libflac": int(lb.size), "bytes_port": int(nb[:4].sum())}
+        else:
+            out["libflac"] = "unavailable on this box (ctypes.util.find_library('FLAC') is None): parity with libFLAC unpinned"
+    except Exception as e:  # the harness must never take the bench down
+        out["libflac"] = f"harness error: {type(e).__name__}: {e}"[:200]
+    return out
 
 
 def make_float_data(torch, n_ch, n_samp, seed, device):
