@@ -257,7 +257,7 @@ def main():
     x = make_data(torch, n_ch, n_samp, 123456789 + rank, dev)
     ws = EncodeWorkspace()
     n_global = n_ch * world
-    gather_state = {"on": world > 1 and not args.no_gather, "error": None, "bytes": 0}
+    gather_state = {"on": world > 1 and not args.no_gather, "error": None, "bytes": 0, "local": 0, "events": []}
 
     def sync():
         if world > 1:
@@ -273,8 +273,13 @@ def main():
             # of the never-before-run RCCL leg is recorded and the remaining steps run without it.
             if gather_state["on"]:
                 try:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                     g_blob, _, _ = fdist.assemble_global(comp, nb.reshape(-1), n_global)
+                    e1.record()
+                    gather_state["events"].append((e0, e1))
                     gather_state["bytes"] = int(g_blob.numel())
+                    gather_state["local"] = int(comp.numel())
                     del g_blob
                 except Exception as e:  # noqa: BLE001
                     gather_state["on"] = False
@@ -392,7 +397,14 @@ def main():
             "decode_Msamples_per_s": round(n_local * world / (dec_seq * 1e-3) / 1e6, 1) if dec_seq > 0 else None,
         }
         if world > 1:
-            out["allgatherv"] = {"in_step": bool(gather_state["on"]), "global_blob_bytes": gather_state["bytes"], "error": gather_state["error"]}
+            ag = {"in_step": bool(gather_state["on"]), "global_blob_bytes": gather_state["bytes"], "error": gather_state["error"]}
+            ev = gather_state["events"][-args.steps:]
+            if gather_state["on"] and ev:
+                # stream time of the assembly (byte counts + blobs) on rank 0, and what that is per GPU in received bytes
+                # (xGMI: 7 links per GPU, one per peer; the transfers of a step all run at once)
+                ag["ms"] = round(float(np.mean([a.elapsed_time(b) for a, b in ev])), 3)
+                ag["received_GBs_per_gpu"] = round((gather_state["bytes"] - gather_state["local"]) / (ag["ms"] * 1e-3) / 1e9, 1) if ag["ms"] > 0 else None
+            out["allgatherv"] = ag
         if cfg5 is not None:
             out["cfg5"] = cfg5
     if not args.no_extra and world == 1:
