@@ -1323,14 +1323,24 @@ FA_GLOBAL __global__ __launch_bounds__(64) FA_K3_WAVES_ATTR void encode_frames_k
                     R.incl = wave_incl_scan_u32(R.lane_len);
                     R.total = (uint32_t)__builtin_amdgcn_readlane((int)R.incl, 63);
                 };
+                // one Rice code whose stop bit lands at bit P: stop bit + k low bits left-aligned in a word (whatever u
+                // holds above bit k is shifted out or falls on the stop bit), funnel-shifted to P mod 32 -- no 64-bit
+                // shift, no mask, no subtraction (the single-pass encoder's row writer, encode_fused.hpp)
+                auto put_code = [&](uint32_t P, uint32_t u, uint32_t shl) __attribute__((always_inline)) {
+                    const uint32_t vL = (u << shl) | 0x80000000u;
+                    uint32_t wi;  // (asm: the compiler turns the bit-field extract into shift + mask and then needs an add)
+                    asm("v_bfe_u32 %0, %1, 5, %2" : "=v"(wi) : "v"(P), "n"(__builtin_ctz((unsigned)kRingWords)));
+                    uint32_t* const w = ring + wi;
+                    atomicOr(w, __builtin_amdgcn_alignbit(0u, vL, P));
+                    atomicOr(w + 1, __builtin_amdgcn_alignbit(vL, 0u, P));  // may be the mirror word
+                };
                 auto rice_put = [&](const RowPrep& R) __attribute__((always_inline)) {
                     const uint32_t k = R.k, kp1 = k + 1u;
-                    const uint32_t onek = 1u << k, mask = onek - 1u;
                     const uint32_t p0 = pos + R.incl - R.lane_len;
                     uint32_t p = p0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        put_bits(p + R.q[e], onek | (R.u[e] & mask), kp1);
+                        put_code(p + R.q[e], R.u[e], 31u - k);
                         p += R.q[e] + kp1;
                     }
                     // (last, so that the four unconditional codes share a basic block with the next row's scan)
