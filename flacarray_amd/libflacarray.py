@@ -522,7 +522,15 @@ class DeviceDecodeIndex:
             self._L.fa_decode_index_destroy(self._h)
             self._h = ctypes.c_void_p(None)
 
-    __del__ = close
+    def __del__(self):
+        import sys
+
+        if sys is None or sys.is_finalizing():  # the HIP runtime may be gone already: the process ends anyway
+            return
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
     def _types(self, to_float):
         torch = _torch()
