@@ -110,6 +110,26 @@ def wrap_encode_i32_threaded(flatdata, n_stream, stream_size, level):
     return _wrap_encode(_lib.lib().encode_i32_threaded, flatdata, n_stream, stream_size, level)
 
 
+def _blocksize_classes(header_bytes):
+    """Streams of one decode call normally share their block size (one array, one level).  A store assembled from
+    several encodes may not -- libFLAC decodes every stream on its own terms (decompress.c:256-305), the GPU decoder
+    takes one block size per launch.  header_bytes: uint8 [n_stream, 12], the first bytes of every stream
+    ("fLaC", STREAMINFO header, min / max block size).  Returns a list of index arrays, one per block size, or None
+    when the headers are not what they should be or all streams agree."""
+    h = np.asarray(header_bytes, dtype=np.uint8)
+    if h.ndim != 2 or h.shape[1] < 12 or h.shape[0] < 2:
+        return None
+    if not (np.all(h[:, 0:4] == np.frombuffer(b"fLaC", np.uint8)) and np.all((h[:, 4] & 0x7F) == 0)):
+        return None
+    bmin = (h[:, 8].astype(np.int64) << 8) | h[:, 9]
+    bmax = (h[:, 10].astype(np.int64) << 8) | h[:, 11]
+    key = bmin * 65536 + bmax
+    kinds = np.unique(key)
+    if kinds.size < 2:
+        return None
+    return [np.flatnonzero(key == k) for k in kinds]
+
+
 def wrap_decode_i32(compressed, starts, nbytes, n_stream, stream_size, first_sample, last_sample, use_threads, _i64=False):
     """libflacarray.pyx:597-653"""
     _lib.require_device()
@@ -125,7 +145,16 @@ def wrap_decode_i32(compressed, starts, nbytes, n_stream, stream_size, first_sam
         bool(use_threads),
     )
     if errcode != 0:
-        raise RuntimeError(f"Decoding failed, return code = {errcode}")
+        # streams of different block sizes in one call: one launch per block size, rows scattered back
+        groups = None
+        if n_stream > 1 and np.all(starts >= 0) and np.all(nbytes >= 12) and np.all(starts + nbytes <= compressed.size):
+            groups = _blocksize_classes(compressed[starts[:, None] + np.arange(12)[None, :]])
+        if groups is None:
+            raise RuntimeError(f"Decoding failed, return code = {errcode}")
+        out2 = output.reshape(n_stream, max(n_decode, 0))
+        for idx in groups:
+            out2[idx] = wrap_decode_i32(compressed, starts[idx], nbytes[idx], int(idx.size), stream_size, first_sample, last_sample,
+                                        use_threads, _i64=_i64).reshape(idx.size, -1)
     return output
 
 
@@ -383,6 +412,28 @@ def encode_flac_device_f32(data, quanta=None, level=5, workspace=None, compact=F
     return compressed, starts.reshape(lead), nbytes.reshape(lead), offsets.reshape(lead), gains.reshape(lead)
 
 
+def _device_regroup(errcode, out, compressed, starts, nbytes, stream_size, first_sample, last_sample, offsets, gains, is_int64):
+    """A failed decode call whose streams differ in block size: one launch per block size (see _blocksize_classes),
+    rows scattered back into `out`.  Anything else raises the reference's error."""
+    torch = _torch()
+    st, nb = starts.reshape(-1), nbytes.reshape(-1)
+    n_stream = st.numel()
+    groups = None
+    if n_stream > 1 and bool(((st >= 0) & (nb >= 12) & (st + nb <= compressed.numel())).all()):
+        groups = _blocksize_classes(compressed[st[:, None] + torch.arange(12, device=st.device)[None, :]].cpu().numpy())
+    if groups is None:
+        raise RuntimeError(f"Decoding failed, return code = {errcode}")
+    out2 = out.reshape(n_stream, -1)
+    for g in groups:
+        gi = torch.from_numpy(g).to(st.device)
+        out2[gi] = decode_flac_device(
+            compressed, st[gi].contiguous(), nb[gi].contiguous(), stream_size, first_sample, last_sample,
+            offsets=None if offsets is None else offsets.reshape(-1)[gi.to(offsets.device)],
+            gains=None if gains is None else gains.reshape(-1)[gi.to(gains.device)], is_int64=is_int64,
+        )
+    return out
+
+
 def decode_flac_device(compressed, starts, nbytes, stream_size, first_sample=-1, last_sample=-1, offsets=None, gains=None,
                        is_int64=False):
     """Decode device-resident streams into an int32 tensor (or float32 when offsets/gains are
@@ -431,7 +482,7 @@ def decode_flac_device(compressed, starts, nbytes, stream_size, first_sample=-1,
                     last_sample, None, _dp(out), _dp(offsets), _dp(gains), _stream_ptr(),
                 )
         if errcode != 0:
-            raise RuntimeError(f"Decoding failed, return code = {errcode}")
+            return _device_regroup(errcode, out, compressed, starts, nbytes, stream_size, first_sample, last_sample, offsets, gains, True)
         return out
     with torch.cuda.device(dev):
         if offsets is None:
@@ -449,7 +500,7 @@ def decode_flac_device(compressed, starts, nbytes, stream_size, first_sample=-1,
                 None, _dp(out), _dp(offsets), _dp(gains), _stream_ptr(),
             )
     if errcode != 0:
-        raise RuntimeError(f"Decoding failed, return code = {errcode}")
+        return _device_regroup(errcode, out, compressed, starts, nbytes, stream_size, first_sample, last_sample, offsets, gains, False)
     return out
 
 

@@ -548,6 +548,37 @@ def test_decode_index_matches_plain_decode(fa, oracle, kind):
         fa.DeviceDecodeIndex(tb, ts + 10**12, tn, n, is_int64=(kind == "i64"))
 
 
+def test_streams_of_different_block_sizes_in_one_call(fa, oracle):
+    """A store put together from encodes at level 0-2 (1152-sample blocks) and 3-8 (4096): libFLAC decodes every
+    stream on its own terms (decompress.c:256-305); here the call falls back to one launch per block size."""
+    import torch
+
+    n = 20000
+    xa, xb = sinusoid_noise_i32(3, n, seed=61), sinusoid_noise_i32(4, n, seed=62)
+    ba, sa, na = oracle.encode_i32(xa, 1)
+    bb, sb, nb = oracle.encode_i32(xb, 5)
+    blob = np.concatenate([ba, bb])
+    st = np.concatenate([sa, sb + ba.size])
+    nbs = np.concatenate([na, nb])
+    order = np.array([4, 0, 5, 1, 6, 2, 3])  # interleave the two kinds
+    st, nbs = st[order].copy(), nbs[order].copy()
+    x = np.concatenate([xa, xb])[order]
+    assert np.array_equal(fa.decode_flac(blob, st, nbs, n), x)
+    assert np.array_equal(fa.decode_flac(blob, st, nbs, n, 1000, 9000), x[:, 1000:9000])
+    dev = torch.device("cuda", 0)
+    tb, ts, tn = (torch.from_numpy(a).to(dev) for a in (blob, st, nbs))
+    assert np.array_equal(fa.decode_flac_device(tb, ts, tn, n).cpu().numpy(), x)
+    off, gain = torch.linspace(-1, 1, 7), torch.linspace(1e-3, 2e-3, 7)
+    got = fa.decode_flac_device(tb, ts, tn, n, 5, 4100, offsets=off, gains=gain)
+    ref = torch.stack([fa.decode_flac_device(tb, ts[i : i + 1], tn[i : i + 1], n, 5, 4100, offsets=off[i : i + 1], gains=gain[i : i + 1])[0] for i in range(7)])
+    assert torch.equal(got, ref)
+    # a store that is damaged rather than mixed still fails
+    bad = blob.copy()
+    bad[int(st[2]) : int(st[2]) + 4] = 0
+    with pytest.raises(RuntimeError, match="Decoding failed"):
+        fa.decode_flac(bad, st, nbs, n)
+
+
 @pytest.mark.parametrize("level,n", [(5, 100000), (0, 50001), (8, 4096 * 3)])
 def test_decode_without_seektable(fa, oracle, level, n):
     """Streams without a SEEKTABLE (what libFLAC writes through the reference, compress.c:337-390)
