@@ -548,6 +548,27 @@ def test_decode_index_matches_plain_decode(fa, oracle, kind):
         fa.DeviceDecodeIndex(tb, ts + 10**12, tn, n, is_int64=(kind == "i64"))
 
 
+def test_rfc9639_example_1_on_the_gpu(fa):
+    """The worked example of RFC 9639 Appendix D.1 (tests/test_oracle.py: self-verifying through its CRC-8, CRC-16 and
+    MD5) through the HIP decoder: a 16-bit stereo frame of one sample with VERBATIM subframes and wasted bits, neither
+    written nor assembled by this repository."""
+    from tests.test_oracle import RFC9639_EXAMPLE_1, RFC9639_EXAMPLE_1_SAMPLES
+
+    blob = np.frombuffer(RFC9639_EXAMPLE_1, dtype=np.uint8).copy()
+    y = fa.decode_flac(blob, np.array([0], np.int64), np.array([blob.size], np.int64), 1, is_int64=True)
+    assert int(y.reshape(-1)[0]) == (RFC9639_EXAMPLE_1_SAMPLES[1] << 32) | RFC9639_EXAMPLE_1_SAMPLES[0]
+    fa.set_decode_verify(True)
+    try:
+        y = fa.decode_flac(blob, np.array([0], np.int64), np.array([blob.size], np.int64), 1, is_int64=True)
+        assert int(y.reshape(-1)[0]) == (RFC9639_EXAMPLE_1_SAMPLES[1] << 32) | RFC9639_EXAMPLE_1_SAMPLES[0]
+        bad = blob.copy()
+        bad[51] ^= 0x10  # a sample bit of the first subframe: only the frame CRC-16 can tell
+        with pytest.raises(RuntimeError, match="Decoding failed"):
+            fa.decode_flac(bad, np.array([0], np.int64), np.array([blob.size], np.int64), 1, is_int64=True)
+    finally:
+        fa.set_decode_verify(False)
+
+
 def test_streams_of_different_block_sizes_in_one_call(fa, oracle):
     """A store put together from encodes at level 0-2 (1152-sample blocks) and 3-8 (4096): libFLAC decodes every
     stream on its own terms (decompress.c:256-305); here the call falls back to one launch per block size."""

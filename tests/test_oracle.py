@@ -18,6 +18,32 @@ def test_crc_known_answers():
     assert crc16(b"123456789") == 0xFEE8  # CRC-16/UMTS check value
 
 
+# RFC 9639, Appendix D.1 ("Decoding Example 1"): a complete FLAC file of one frame with one 16-bit stereo sample.  Not
+# written by this repository, and self-verifying: the frame header CRC-8 (0xbf), the frame CRC-16 (0xaa9a) and the MD5
+# of the decoded samples stored in STREAMINFO all have to agree with a transcription for it to pass.
+RFC9639_EXAMPLE_1 = bytes.fromhex(
+    "664c6143" "80000022" "1000" "1000" "00000f" "00000f" "0ac442f0" "00000001" "3e84b41807dc690307586a3dad1a2e0f"
+    "fff869180000bf" "0358fd" "03128b" "aa9a"
+)
+RFC9639_EXAMPLE_1_SAMPLES = (25588, 10416)  # left, right (VERBATIM subframes with 2 and 4 wasted bits)
+
+
+def test_rfc9639_example_1_is_self_consistent_and_decodes(oracle):
+    import hashlib
+    import struct
+
+    b = RFC9639_EXAMPLE_1
+    assert crc8(b[42:48]) == b[48] == 0xBF
+    assert crc16(b[42:55]) == int.from_bytes(b[55:57], "big") == 0xAA9A
+    assert hashlib.md5(struct.pack("<hh", *RFC9639_EXAMPLE_1_SAMPLES)).digest() == b[26:42]
+    samples, info = pyflac.decode_stream(b)  # the independent pure-Python decoder
+    assert tuple(samples) == RFC9639_EXAMPLE_1_SAMPLES and info["channels"] == 2 and info["bps"] == 16
+    # the oracle reads two-channel streams the way the reference's int64 path does: (channel 1 << 32) | low word of channel 0
+    blob = np.frombuffer(b, dtype=np.uint8).copy()
+    y = oracle.decode_i64(blob, np.array([0], np.int64), np.array([len(b)], np.int64), 1)
+    assert int(y[0, 0]) == (RFC9639_EXAMPLE_1_SAMPLES[1] << 32) | RFC9639_EXAMPLE_1_SAMPLES[0]
+
+
 def test_golden_file_matches_generator():
     v = np.load(GOLDEN)
     g = build_golden()
