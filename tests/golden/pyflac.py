@@ -91,7 +91,7 @@ def decode_stream(data):
             bs = b.u(16) + 1
         else:
             bs = 256 << (bsc - 8)
-        assert src == 9
+        assert src <= 11  # codes 12-14 carry extra header bytes (not needed by any vector here), 15 is invalid
         hdr_end = b.pos // 8
         assert b.u(8) == crc8(data[start:hdr_end]), "CRC-8"
         bps0 = {0: info["bps"], 1: 8, 2: 12, 4: 16, 5: 20, 6: 24, 7: 32}[ssc]

@@ -548,25 +548,33 @@ def test_decode_index_matches_plain_decode(fa, oracle, kind):
         fa.DeviceDecodeIndex(tb, ts + 10**12, tn, n, is_int64=(kind == "i64"))
 
 
-def test_rfc9639_example_1_on_the_gpu(fa):
-    """The worked example of RFC 9639 Appendix D.1 (tests/test_oracle.py: self-verifying through its CRC-8, CRC-16 and
-    MD5) through the HIP decoder: a 16-bit stereo frame of one sample with VERBATIM subframes and wasted bits, neither
-    written nor assembled by this repository."""
-    from tests.test_oracle import RFC9639_EXAMPLE_1, RFC9639_EXAMPLE_1_SAMPLES
+@pytest.mark.parametrize("name", ["example1", "example2", "example3"])
+def test_rfc9639_worked_examples_on_the_gpu(fa, name):
+    """The worked examples of RFC 9639 Appendix D (tests/golden/rfc9639.py: self-verifying through their CRC-8s,
+    CRC-16s and MD5, checked in tests/test_oracle.py) through the HIP decoder and its CRC-16 verifier: VERBATIM with
+    wasted bits, side/right stereo with FIXED subframes and a short last frame behind three metadata blocks, 8-bit LPC
+    with an escaped partition -- streams this repository neither wrote nor assembled."""
+    from tests.test_oracle import _rfc_samples
 
-    blob = np.frombuffer(RFC9639_EXAMPLE_1, dtype=np.uint8).copy()
-    y = fa.decode_flac(blob, np.array([0], np.int64), np.array([blob.size], np.int64), 1, is_int64=True)
-    assert int(y.reshape(-1)[0]) == (RFC9639_EXAMPLE_1_SAMPLES[1] << 32) | RFC9639_EXAMPLE_1_SAMPLES[0]
-    fa.set_decode_verify(True)
-    try:
-        y = fa.decode_flac(blob, np.array([0], np.int64), np.array([blob.size], np.int64), 1, is_int64=True)
-        assert int(y.reshape(-1)[0]) == (RFC9639_EXAMPLE_1_SAMPLES[1] << 32) | RFC9639_EXAMPLE_1_SAMPLES[0]
-        bad = blob.copy()
-        bad[51] ^= 0x10  # a sample bit of the first subframe: only the frame CRC-16 can tell
-        with pytest.raises(RuntimeError, match="Decoding failed"):
-            fa.decode_flac(bad, np.array([0], np.int64), np.array([blob.size], np.int64), 1, is_int64=True)
-    finally:
-        fa.set_decode_verify(False)
+    data, x = _rfc_samples(name)
+    n = x.shape[1]
+    blob = np.frombuffer(data, dtype=np.uint8).copy()
+    st, nb = np.array([0], np.int64), np.array([blob.size], np.int64)
+    i64 = x.shape[0] == 2
+    want = ((x[1] << 32) | (x[0] & 0xFFFFFFFF)) if i64 else x[0].astype(np.int32)
+    for verify in (False, True):
+        fa.set_decode_verify(verify)
+        try:
+            assert np.array_equal(fa.decode_flac(blob, st, nb, n, is_int64=i64).reshape(-1), want)
+            if n > 2:
+                assert np.array_equal(fa.decode_flac(blob, st, nb, n, 2, n - 1, is_int64=i64).reshape(-1), want[2 : n - 1])
+            if verify:
+                bad = blob.copy()
+                bad[blob.size - 5] ^= 0x04  # a residual / sample bit of the last frame: only its CRC-16 can tell
+                with pytest.raises(RuntimeError, match="Decoding failed"):
+                    fa.decode_flac(bad, st, nb, n, is_int64=i64)
+        finally:
+            fa.set_decode_verify(False)
 
 
 def test_streams_of_different_block_sizes_in_one_call(fa, oracle):

@@ -18,30 +18,46 @@ def test_crc_known_answers():
     assert crc16(b"123456789") == 0xFEE8  # CRC-16/UMTS check value
 
 
-# RFC 9639, Appendix D.1 ("Decoding Example 1"): a complete FLAC file of one frame with one 16-bit stereo sample.  Not
-# written by this repository, and self-verifying: the frame header CRC-8 (0xbf), the frame CRC-16 (0xaa9a) and the MD5
-# of the decoded samples stored in STREAMINFO all have to agree with a transcription for it to pass.
-RFC9639_EXAMPLE_1 = bytes.fromhex(
-    "664c6143" "80000022" "1000" "1000" "00000f" "00000f" "0ac442f0" "00000001" "3e84b41807dc690307586a3dad1a2e0f"
-    "fff869180000bf" "0358fd" "03128b" "aa9a"
-)
-RFC9639_EXAMPLE_1_SAMPLES = (25588, 10416)  # left, right (VERBATIM subframes with 2 and 4 wasted bits)
-
-
-def test_rfc9639_example_1_is_self_consistent_and_decodes(oracle):
+def _rfc_samples(name):
+    """Decode an RFC 9639 Appendix D example with the independent decoder and check everything the file says about
+    itself: frame header CRC-8s, frame CRC-16s, and the MD5 of the samples (interleaved, little endian)."""
     import hashlib
     import struct
 
-    b = RFC9639_EXAMPLE_1
-    assert crc8(b[42:48]) == b[48] == 0xBF
-    assert crc16(b[42:55]) == int.from_bytes(b[55:57], "big") == 0xAA9A
-    assert hashlib.md5(struct.pack("<hh", *RFC9639_EXAMPLE_1_SAMPLES)).digest() == b[26:42]
-    samples, info = pyflac.decode_stream(b)  # the independent pure-Python decoder
-    assert tuple(samples) == RFC9639_EXAMPLE_1_SAMPLES and info["channels"] == 2 and info["bps"] == 16
-    # the oracle reads two-channel streams the way the reference's int64 path does: (channel 1 << 32) | low word of channel 0
-    blob = np.frombuffer(b, dtype=np.uint8).copy()
-    y = oracle.decode_i64(blob, np.array([0], np.int64), np.array([len(b)], np.int64), 1)
-    assert int(y[0, 0]) == (RFC9639_EXAMPLE_1_SAMPLES[1] << 32) | RFC9639_EXAMPLE_1_SAMPLES[0]
+    from tests.golden import rfc9639
+
+    data, channels, bps, n, frames = rfc9639.EXAMPLES[name]
+    ends = list(frames[1:]) + [len(data)]
+    for f0, f1 in zip(frames, ends):
+        assert data[f0] == 0xFF and data[f0 + 1] == 0xF8
+        assert crc8(data[f0 : f0 + 6]) == data[f0 + 6], (name, f0)  # (every header here is 6 bytes + its CRC-8)
+        assert crc16(data[f0 : f1 - 2]) == int.from_bytes(data[f1 - 2 : f1], "big"), (name, f0)
+    samples, info = pyflac.decode_stream(data)
+    assert (info["channels"], info["bps"], info["total"]) == (channels, bps, n)
+    fmt = {8: "b", 16: "h"}[bps]
+    assert hashlib.md5(struct.pack(f"<{len(samples)}{fmt}", *samples)).digest() == data[26:42], name
+    x = np.array(samples, dtype=np.int64).reshape(n, channels).T  # [channel][sample]
+    return data, x
+
+
+@pytest.mark.parametrize("name", ["example1", "example2", "example3"])
+def test_rfc9639_worked_examples(oracle, name):
+    """Known answers that nobody here wrote: the oracle decoder against the RFC's own files (full decode and slices)."""
+    data, x = _rfc_samples(name)
+    n = x.shape[1]
+    blob = np.frombuffer(data, dtype=np.uint8).copy()
+    st, nb = np.array([0], np.int64), np.array([len(data)], np.int64)
+    if x.shape[0] == 1:
+        assert np.array_equal(oracle.decode_i32(blob, st, nb, n)[0], x[0])
+        assert np.array_equal(oracle.decode_i32(blob, st, nb, n, 3, 21)[0], x[0, 3:21])
+    else:
+        # two-channel streams the way the reference's int64 path reads them: (channel 1 << 32) | low word of channel 0
+        want = (x[1] << 32) | (x[0] & 0xFFFFFFFF)
+        assert np.array_equal(oracle.decode_i64(blob, st, nb, n)[0], want)
+        if n > 2:
+            assert np.array_equal(oracle.decode_i64(blob, st, nb, n, 5, 18)[0], want[5:18])
+    if name == "example1":
+        assert tuple(x[:, 0]) == (25588, 10416)
 
 
 def test_golden_file_matches_generator():
