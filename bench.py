@@ -385,7 +385,9 @@ def main():
                 "traffic_unit": "GB per launch; constant from the newest committed PMC pass (profiles/r*_traffic.json), not measured in this run",
                 "algorithmic_bytes_per_sample": round(4 + c_bytes, 4),
                 # what actually limits the kernel (profiles/*_pmc_sq_insts.csv): instruction issue, not HBM
-                "limiter": "valu_issue",
+                # not HBM: instruction issue at the occupancy the kernels' registers / LDS allow (K3F: three waves per SIMD, each
+                # vector-active 27 % of its life and waiting 16 % of it for its byte offset; K7: two waves, 35 % each) -- DESIGN 4
+                "limiter": "instruction_issue_at_limited_occupancy",
                 # the unit is the whole sequence -- HIP events around begin..finish (K3+K4+K5, host gaps
                 # included) and around K6+K7, on the launch stream
                 "encode_sequence": {"ms": round(enc_seq, 3), "achieved": gbs(enc_seq), "frac": round(gbs(enc_seq) / HBM_PEAK_GBS, 4) if enc_seq > 0 else None},
