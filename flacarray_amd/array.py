@@ -9,6 +9,8 @@ in flacarray_amd.dist).  `read_slices` is an addition: one batched launch for ma
 (stream, sample-range) requests, which the reference can only serve one call at a time.
 """
 import copy
+from dataclasses import dataclass, field
+from typing import Any, Optional, Tuple
 
 import numpy as np
 
@@ -16,177 +18,124 @@ from .compress import array_compress
 from .decompress import array_decompress_slice
 from .utils import log
 
+_KINDS = {"int32": (False, False), "int64": (True, False), "float32": (False, True), "float64": (True, True)}
+
+
+@dataclass(frozen=True)
+class _Store:
+    """Everything a FlacArray knows about its compressed store, validated once and never mutated.
+
+    The five arrays are the reference's triple (+ the two quantisation vectors); all other fields are derived
+    from `shape` / `dtype` by `_Store.build`.  A single process holds the whole array here, so each `global_*`
+    quantity equals its local twin (the reference fills them through mpi.py:93-187 when a communicator is given).
+    """
+
+    shape: Tuple[int, ...]            # the user's shape (a 1-D array stays 1-D)
+    global_shape: Tuple[int, ...]
+    dtype: np.dtype
+    blob: Any                         # uint8, all streams back to back
+    starts: Any                       # int64 over the leading shape
+    nbytes_per_stream: Any            # int64 over the leading shape
+    offsets: Optional[Any]            # float data only
+    gains: Optional[Any]
+    dist: Any = None
+    # derived
+    single: bool = field(default=False)          # the original was 1-D: one stream, results are flattened
+    grid: Tuple[int, ...] = field(default=())     # shape with the stream axis made explicit
+    kind: str = field(default="int32")
+    wide: bool = field(default=False)             # 64-bit samples: two FLAC channels per stream
+
+    @classmethod
+    def build(cls, shape, global_shape, dtype, blob, starts, nbytes, offsets, gains, dist=None):
+        dt = np.dtype(dtype)
+        kind = next((k for k in _KINDS if dt == np.dtype(k)), None)
+        if kind is None:
+            raise RuntimeError(f"Unsupported dtype '{dt}'")
+        shp = tuple(int(n) for n in shape)
+        single = len(shp) == 1
+        grid = (1,) + shp if single else shp
+        gshape = tuple(int(n) for n in global_shape) if global_shape is not None else grid
+        return cls(shp, gshape, dt, blob, starts, nbytes, offsets, gains, dist, single, grid, kind, _KINDS[kind][0])
+
+    def clone(self):
+        dup = copy.deepcopy
+        return _Store.build(self.shape, self.global_shape, self.dtype, dup(self.blob), dup(self.starts), dup(self.nbytes_per_stream),
+                            dup(self.offsets), dup(self.gains), dup(self.dist))
+
+    # what the accessors below hand out
+    lead = property(lambda s: s.grid[:-1])
+    glead = property(lambda s: s.global_shape[:-1])
+    samples = property(lambda s: s.grid[-1])
+    blob_bytes = property(lambda s: int(s.blob.nbytes))
+    count = property(lambda s: int(np.prod(s.grid[:-1], dtype=np.int64)))
+    gcount = property(lambda s: int(np.prod(s.global_shape[:-1], dtype=np.int64)))
+
+
+# public read-only attribute -> (field or derived property of _Store, one-line description)
+_ACCESSORS = {
+    "shape": ("shape", "Shape of the array this object decompresses to."),
+    "global_shape": ("global_shape", "Shape across all processes (equal to the local one without a communicator)."),
+    "leading_shape": ("lead", "Local shape without the compressed (last) axis."),
+    "global_leading_shape": ("glead", "Global shape without the compressed axis."),
+    "stream_size": ("samples", "Number of samples in every stream."),
+    "nbytes": ("blob_bytes", "Size of the local compressed bytes."),
+    "global_nbytes": ("blob_bytes", "Size of the compressed bytes of all processes."),
+    "nstreams": ("count", "Number of local streams."),
+    "global_nstreams": ("gcount", "Number of streams of all processes."),
+    "compressed": ("blob", "uint8 array: every stream's FLAC bytes, back to back."),
+    "stream_starts": ("starts", "int64 byte offset of each stream inside `compressed`."),
+    "stream_nbytes": ("nbytes_per_stream", "int64 byte count of each stream."),
+    "global_stream_starts": ("starts", "Stream offsets inside the global byte range."),
+    "global_stream_nbytes": ("nbytes_per_stream", "Stream byte counts of all processes."),
+    "stream_offsets": ("offsets", "Per-stream offset removed before quantisation (float data; else None)."),
+    "stream_gains": ("gains", "Per-stream scale applied at quantisation (float data; else None)."),
+    "mpi_dist": ("dist", "Ranges of the leading axis held by each process (None here)."),
+    "dtype": ("dtype", "numpy dtype of the decompressed samples."),
+    "typestr": ("kind", "dtype as one of 'int32', 'int64', 'float32', 'float64'."),
+}
+
+
+def _store_reader(attr, doc):
+    return property(lambda self: getattr(self._st, attr), doc=doc)
+
 
 class FlacArray:
     """FLAC compressed array representation; the last axis is the compressed one.
 
     Constructed directly only to copy (`FlacArray(other)`); use `from_array` otherwise.
+    Keyword arguments are those of the reference constructor (array.py:78-90).
     """
 
-    def __init__(
-        self,
-        other,
-        shape=None,
-        global_shape=None,
-        compressed=None,
-        dtype=None,
-        stream_starts=None,
-        stream_nbytes=None,
-        stream_offsets=None,
-        stream_gains=None,
-        mpi_comm=None,
-        mpi_dist=None,
-    ):
-        if other is not None:
-            self._shape = copy.deepcopy(other._shape)
-            self._global_shape = copy.deepcopy(other._global_shape)
-            self._compressed = copy.deepcopy(other._compressed)
-            self._dtype = np.dtype(other._dtype)
-            self._stream_starts = copy.deepcopy(other._stream_starts)
-            self._stream_nbytes = copy.deepcopy(other._stream_nbytes)
-            self._stream_offsets = copy.deepcopy(other._stream_offsets)
-            self._stream_gains = copy.deepcopy(other._stream_gains)
-            self._mpi_dist = copy.deepcopy(other._mpi_dist)
-            self._mpi_comm = other._mpi_comm  # (a copy starts without the HBM mirror of `other`)
-        else:
-            self._shape = tuple(shape)
-            if global_shape is not None:
-                self._global_shape = tuple(global_shape)
-            else:  # single process: mpi.py:109-117 (a 1-D array is one stream: global shape (1, n))
-                self._global_shape = (1, self._shape[0]) if len(self._shape) == 1 else self._shape
-            self._compressed = compressed
-            self._dtype = np.dtype(dtype)
-            self._stream_starts = stream_starts
-            self._stream_nbytes = stream_nbytes
-            self._stream_offsets = stream_offsets
-            self._stream_gains = stream_gains
-            self._mpi_comm = mpi_comm
-            self._mpi_dist = mpi_dist
-        if self._mpi_comm is not None:
+    def __init__(self, other, shape=None, global_shape=None, compressed=None, dtype=None, stream_starts=None,
+                 stream_nbytes=None, stream_offsets=None, stream_gains=None, mpi_comm=None, mpi_dist=None):
+        if (other._comm if other is not None else mpi_comm) is not None:
             raise NotImplementedError("mpi4py communicators are not supported; see flacarray_amd.dist for multi-GPU sharding")
-        self._resident = None  # device copies of (compressed, starts, nbytes, offsets, gains): see to_device()
-        self._init_params()
+        self._comm = None
+        self._st = other._st.clone() if other is not None else _Store.build(
+            shape, global_shape, dtype, compressed, stream_starts, stream_nbytes, stream_offsets, stream_gains, mpi_dist)
+        self._resident = None  # device copies of (compressed, starts, nbytes, offsets, gains): see to_device(); never copied
 
-    def _init_params(self):
-        # a 1-D original keeps its flattened shape; internally there is always a stream axis
-        if len(self._shape) == 1:
-            self._flatten_single = True
-            self._local_shape = (1, self._shape[0])
-        else:
-            self._flatten_single = False
-            self._local_shape = self._shape
-        self._local_nbytes = self._compressed.nbytes
-        self._global_nbytes = self._local_nbytes
-        self._global_proc_nbytes = [self._local_nbytes]
-        self._global_stream_starts = self._stream_starts
-        self._global_stream_nbytes = self._stream_nbytes
-        self._leading_shape = self._local_shape[:-1]
-        self._global_leading_shape = self._global_shape[:-1]
-        self._stream_size = self._local_shape[-1]
-        self._local_nstreams = int(np.prod(self._leading_shape))
-        self._global_nstreams = int(np.prod(self._global_leading_shape)) if len(self._global_leading_shape) else 1
-        self._typestr = self._dtype_str(self._dtype)
-        self._is_int64 = self._dtype == np.dtype(np.int64) or self._dtype == np.dtype(np.float64)
+    mpi_comm = property(lambda self: self._comm, doc="Always None: distribution goes through flacarray_amd.dist.")
+    global_process_nbytes = property(lambda self: [self._st.blob_bytes], doc="Compressed bytes held by each process.")
 
-    @staticmethod
-    def _dtype_str(dt):
-        for name in ("float64", "float32", "int64", "int32"):
-            if dt == np.dtype(name):
-                return name
-        raise RuntimeError(f"Unsupported dtype '{dt}'")
-
-    # ---- shapes of the decompressed array ----
-    @property
-    def shape(self):
-        """The shape of the local, uncompressed array."""
-        return self._shape
-
-    @property
-    def global_shape(self):
-        return self._global_shape
-
-    @property
-    def leading_shape(self):
-        """The local shape of leading uncompressed dimensions."""
-        return self._leading_shape
-
-    @property
-    def global_leading_shape(self):
-        return self._global_leading_shape
-
-    @property
-    def stream_size(self):
-        """The uncompressed length of each stream."""
-        return self._stream_size
-
-    # ---- properties of the compressed data ----
-    @property
-    def nbytes(self):
-        """Bytes used by the compressed data."""
-        return self._local_nbytes
-
-    @property
-    def global_nbytes(self):
-        return self._global_nbytes
-
-    @property
-    def global_process_nbytes(self):
-        return self._global_proc_nbytes
-
-    @property
-    def nstreams(self):
-        return self._local_nstreams
-
-    @property
-    def global_nstreams(self):
-        return self._global_nstreams
-
-    @property
-    def compressed(self):
-        """The concatenated raw bytes of all streams."""
-        return self._compressed
-
-    @property
-    def stream_starts(self):
-        return self._stream_starts
-
-    @property
-    def stream_nbytes(self):
-        return self._stream_nbytes
-
-    @property
-    def global_stream_starts(self):
-        return self._global_stream_starts
-
-    @property
-    def global_stream_nbytes(self):
-        return self._global_stream_nbytes
-
-    @property
-    def stream_offsets(self):
-        """The value subtracted from each stream during conversion to int32."""
-        return self._stream_offsets
-
-    @property
-    def stream_gains(self):
-        """The gain factor for each stream during conversion to int32."""
-        return self._stream_gains
-
-    @property
-    def mpi_comm(self):
-        return self._mpi_comm
-
-    @property
-    def mpi_dist(self):
-        return self._mpi_dist
-
-    @property
-    def dtype(self):
-        return self._dtype
-
-    @property
-    def typestr(self):
-        return self._typestr
+    # the names the rest of this class uses for the store's fields
+    _shape = property(lambda self: self._st.shape)
+    _global_shape = property(lambda self: self._st.global_shape)
+    _local_shape = property(lambda self: self._st.grid)
+    _leading_shape = property(lambda self: self._st.lead)
+    _global_leading_shape = property(lambda self: self._st.glead)
+    _stream_size = property(lambda self: self._st.samples)
+    _flatten_single = property(lambda self: self._st.single)
+    _compressed = property(lambda self: self._st.blob)
+    _stream_starts = property(lambda self: self._st.starts)
+    _global_stream_starts = property(lambda self: self._st.starts)
+    _stream_nbytes = property(lambda self: self._st.nbytes_per_stream)
+    _stream_offsets = property(lambda self: self._st.offsets)
+    _stream_gains = property(lambda self: self._st.gains)
+    _dtype = property(lambda self: self._st.dtype)
+    _typestr = property(lambda self: self._st.kind)
+    _is_int64 = property(lambda self: self._st.wide)
+    _local_nbytes = property(lambda self: self._st.blob_bytes)
 
     # ---- numpy-style selection -> decode ----
     def _plan_selection(self, raw_key):
@@ -319,12 +268,15 @@ class FlacArray:
         if self._resident is not None:
             arr, _ = self._decode_resident(keep, first, last)
             return arr.reshape(shape)
-        arr, _ = array_decompress_slice(
-            self._compressed, self._stream_size, self._stream_starts, self._stream_nbytes, stream_offsets=self._stream_offsets,
-            stream_gains=self._stream_gains, keep=keep, first_stream_sample=first, last_stream_sample=last,
-            is_int64=self._is_int64,
-        )
+        arr, _ = self._decode_host(keep, first, last)
         return arr.reshape(shape)
+
+    def _decode_host(self, keep, first, last, **extra):
+        """array_decompress_slice (decompress.py:18) over this store: bytes go up, samples come back."""
+        st = self._st
+        return array_decompress_slice(st.blob, st.samples, st.starts, st.nbytes_per_stream, stream_offsets=st.offsets,
+                                      stream_gains=st.gains, keep=keep, first_stream_sample=first, last_stream_sample=last,
+                                      is_int64=st.wide, **extra)
 
     def __delitem__(self, key):
         raise RuntimeError("Cannot delete individual streams")
@@ -358,39 +310,22 @@ class FlacArray:
         the whole stream).  `keep`: bool mask over the leading shape; the result is then the
         2-D array of kept streams (and their indices if `keep_indices`).
         """
-        first_samp = None
-        last_samp = None
+        span = None
         if stream_slice is not None:
-            if stream_slice.step is not None and stream_slice.step != 1:
+            if stream_slice.step not in (None, 1):
                 raise RuntimeError("Only stream slices with a step size of 1 are supported")
-            first_samp, last_samp, _ = stream_slice.indices(self._stream_size)
+            span = stream_slice.indices(self._stream_size)[:2]
         if self._resident is not None:
-            f, l = (-1, -1) if first_samp is None else (first_samp, last_samp)
-            if f >= 0 and l <= f:
+            lo, hi = span if span is not None else (-1, -1)
+            if lo >= 0 and hi <= lo:
                 raise RuntimeError("first_sample is larger than last_sample")
-            arr, indices = self._decode_resident(keep, f, l)
+            arr, indices = self._decode_resident(keep, lo, hi)
             if keep is None:
-                arr = arr.reshape(self._shape[:-1] + (arr.shape[-1],)) if not self._flatten_single else arr.reshape(-1)
-            if keep is not None and keep_indices:
-                return (arr, indices)
-            return arr
-        arr, indices = array_decompress_slice(
-            self._compressed,
-            self._stream_size,
-            self._stream_starts,
-            self._stream_nbytes,
-            stream_offsets=self._stream_offsets,
-            stream_gains=self._stream_gains,
-            keep=keep,
-            first_stream_sample=first_samp,
-            last_stream_sample=last_samp,
-            is_int64=self._is_int64,
-            use_threads=use_threads,
-            no_flatten=(not self._flatten_single),
-        )
-        if keep is not None and keep_indices:
-            return (arr, indices)
-        return arr
+                arr = arr.reshape(-1) if self._flatten_single else arr.reshape(self._shape[:-1] + (arr.shape[-1],))
+        else:
+            lo, hi = span if span is not None else (None, None)
+            arr, indices = self._decode_host(keep, lo, hi, use_threads=use_threads, no_flatten=not self._flatten_single)
+        return (arr, indices) if (keep is not None and keep_indices) else arr
 
     def read_slices(self, streams, first, count, as_tensor=False):
         """Batched random access (addition to the reference API).
@@ -447,18 +382,9 @@ class FlacArray:
             comp, st, nb = encode_flac_device(data.contiguous(), level=level, compact=True)
         else:
             raise ValueError(f"Unsupported data type '{data.dtype}'")
-        shape = tuple(data.shape)
-        out = FlacArray(
-            None,
-            shape=shape,
-            global_shape=(1, shape[0]) if len(shape) == 1 else shape,
-            compressed=comp.cpu().numpy(),
-            dtype=np.dtype(str(data.dtype).replace("torch.", "")),
-            stream_starts=st.cpu().numpy(),
-            stream_nbytes=nb.cpu().numpy(),
-            stream_offsets=None if offsets is None else offsets.cpu().numpy(),
-            stream_gains=None if gains is None else gains.cpu().numpy(),
-        )
+        host = lambda t: None if t is None else t.cpu().numpy()  # noqa: E731
+        out = cls._assemble(tuple(data.shape), None, np.dtype(str(data.dtype).replace("torch.", "")), host(comp), host(st), host(nb),
+                            host(offsets), host(gains))
         out._resident = {
             "device": data.device, "compressed": comp, "starts": st.reshape(-1), "nbytes": nb.reshape(-1),
             "offsets": None if offsets is None else offsets.reshape(-1), "gains": None if gains is None else gains.reshape(-1),
@@ -470,41 +396,27 @@ class FlacArray:
         """Construct a FlacArray from a numpy ndarray (array.py:587-637)."""
         if mpi_comm is not None:
             raise NotImplementedError("mpi4py communicators are not supported; see flacarray_amd.dist")
-        compressed, starts, nbytes, offsets, gains = array_compress(
-            arr, level=level, quanta=quanta, precision=precision, use_threads=use_threads
-        )
-        return FlacArray(
-            None,
-            shape=arr.shape,
-            global_shape=(1, arr.shape[0]) if arr.ndim == 1 else arr.shape,  # global_array_properties, mpi.py:109-117
-            compressed=compressed,
-            dtype=arr.dtype,
-            stream_starts=starts,
-            stream_nbytes=nbytes,
-            stream_offsets=offsets,
-            stream_gains=gains,
-            mpi_comm=None,
-            mpi_dist=None,
-        )
+        pieces = array_compress(arr, level=level, quanta=quanta, precision=precision, use_threads=use_threads)
+        return cls._assemble(arr.shape, None, arr.dtype, *pieces)
+
+    @classmethod
+    def _assemble(cls, shape, global_shape, dtype, blob, starts, nbytes, offsets, gains):
+        """A FlacArray around an existing (bytes, starts, nbytes, offsets, gains) store; without a global shape the
+        array is the whole array (global_array_properties, mpi.py:109-117: a 1-D array counts as one stream)."""
+        shape = tuple(shape)
+        if global_shape is None:
+            global_shape = (1,) + shape if len(shape) == 1 else shape
+        return cls(None, shape=shape, global_shape=global_shape, compressed=blob, dtype=dtype, stream_starts=starts,
+                   stream_nbytes=nbytes, stream_offsets=offsets, stream_gains=gains)
 
     def write_hdf5(self, hgrp):
         """Write the compressed representation to an open HDF5 group (array.py:639-682), format
         version 1 (flacarray_amd/hdf5.py)."""
         from .hdf5 import write_compressed
 
-        write_compressed(
-            hgrp,
-            self._leading_shape,
-            self._global_leading_shape,
-            self._stream_size,
-            self._stream_starts,
-            self._global_stream_starts,
-            self._stream_nbytes,
-            self._stream_offsets,
-            self._stream_gains,
-            self._compressed,
-            2 if self._is_int64 else 1,
-        )
+        st = self._st
+        write_compressed(hgrp, st.lead, st.glead, st.samples, st.starts, st.starts, st.nbytes_per_stream, st.offsets, st.gains,
+                         st.blob, 2 if st.wide else 1)
 
     @classmethod
     def read_hdf5(cls, hgrp, keep=None, mpi_comm=None, mpi_dist=None, no_flatten=False):
@@ -513,26 +425,11 @@ class FlacArray:
         from .hdf5 import read_compressed
         from .utils import compressed_dtype
 
-        (local_shape, global_shape, compressed, n_channels, stream_starts, stream_nbytes, stream_offsets, stream_gains,
-         mpi_dist, keep_indices) = read_compressed(hgrp, keep=keep, mpi_comm=mpi_comm, mpi_dist=mpi_dist)
-        dt = compressed_dtype(n_channels, stream_offsets, stream_gains)
-        if (len(local_shape) == 2 and local_shape[0] == 1) and not no_flatten:
-            shape = (local_shape[1],)
-        else:
-            shape = local_shape
-        return FlacArray(
-            None,
-            shape=shape,
-            global_shape=global_shape,
-            compressed=compressed,
-            dtype=dt,
-            stream_starts=stream_starts,
-            stream_nbytes=stream_nbytes,
-            stream_offsets=stream_offsets,
-            stream_gains=stream_gains,
-            mpi_comm=None,
-            mpi_dist=None,
-        )
+        got = read_compressed(hgrp, keep=keep, mpi_comm=mpi_comm, mpi_dist=mpi_dist)
+        local, whole, blob, n_channels, starts, nbytes, offsets, gains = got[:8]
+        if len(local) == 2 and local[0] == 1 and not no_flatten:
+            local = (local[1],)  # a single stream reads back as the 1-D array it was written from
+        return cls._assemble(local, whole, compressed_dtype(n_channels, offsets, gains), blob, starts, nbytes, offsets, gains)
 
     def write_zarr(self, zgrp):
         """Write the compressed representation to an open Zarr group (array.py:766-804); same schema as HDF5."""
@@ -542,3 +439,8 @@ class FlacArray:
     def read_zarr(cls, zgrp, keep=None, mpi_comm=None, mpi_dist=None, no_flatten=False):
         """Construct a FlacArray from a Zarr group (array.py:806-884)."""
         return cls.read_hdf5(zgrp, keep=keep, mpi_comm=mpi_comm, mpi_dist=mpi_dist, no_flatten=no_flatten)
+
+
+for _name, (_attr, _doc) in _ACCESSORS.items():
+    setattr(FlacArray, _name, _store_reader(_attr, _doc))
+del _name, _attr, _doc

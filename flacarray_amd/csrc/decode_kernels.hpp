@@ -548,6 +548,9 @@ constexpr int kTopup = kChunkBytes / 8;               // samples between top-ups
 constexpr int kLaneStride = 64;  // word j of lane l lives at j*64 + l: the bank depends on the lane only
 
 constexpr int kFlagNeed16 = 1, kFlagNeed32 = 2;
+__device__ __forceinline__ int4 shl4(const int4& v, int n) {
+    return make_int4((int)((uint32_t)v.x << n), (int)((uint32_t)v.y << n), (int)((uint32_t)v.z << n), (int)((uint32_t)v.w << n));
+}
 
 __device__ __forceinline__ void ring_load_chunk(const uint8_t* cbase, const uint8_t* lim16, uint32_t* ring, uint32_t ci) {
     const uint8_t* q = cbase + (size_t)ci * kChunkBytes;
@@ -590,9 +593,18 @@ __device__ __forceinline__ void chunk_store(uint32_t* ring, uint32_t ci, const C
 // the three ring words starting at the word that holds bit (bitpos - 1): with off' = ((bitpos-1) & 31) + 1
 // in 1..32 the window is ((w0:w1:w2) << off'), i.e. v_alignbit_b32 with a shift of 32 - off' in 0..31
 // (bitpos >= 8 always: the frame starts at least one byte after its chunk base)
-__device__ __forceinline__ void ring_words(const uint32_t* ring, uint32_t bitpos, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
-    const uint32_t wi = ((bitpos - 1) >> 5) & (kRingW - 1);
-    w0 = ring[wi * kLaneStride]; w1 = ring[(wi + 1) * kLaneStride]; w2 = ring[(wi + 2) * kLaneStride];
+// `lane4` is the LDS byte address of the lane's ring word 0 (the ring image starts at a multiple of 64 x kRingW x 4
+// bytes, checked by the kernel): the address of word wi is lane4 | (wi << 8), two instructions from bitpos -- the
+// compiler's own sequence needs three, because a VOP3 instruction takes no literal on gfx9 and it does not think of
+// keeping the mask in a scalar register.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+constexpr uint32_t kRingAddrMask = (uint32_t)(kRingW - 1) << 8;
+__device__ __forceinline__ void ring_words(uint32_t lane4, uint32_t bitpos, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
+    static_assert(kLaneStride == 64, "word wi of a lane lies 256 wi bytes behind its word 0");
+    uint32_t t, ad;
+    asm("v_add_lshl_u32 %0, %2, -1, 3\n\tv_and_or_b32 %1, %0, %3, %4" : "=&v"(t), "=v"(ad) : "v"(bitpos), "s"(kRingAddrMask), "v"(lane4));
+    const lds_u32* p = (const lds_u32*)(uintptr_t)ad;
+    w0 = p[0]; w1 = p[kLaneStride]; w2 = p[2 * kLaneStride];
 }
 // bits [bitpos, bitpos+32) -> A and [bitpos+32, bitpos+64) -> B
 __device__ __forceinline__ void ring_window(const uint32_t* ring, uint32_t bitpos, uint32_t& A, uint32_t& B) {
@@ -719,13 +731,20 @@ __global__ __launch_bounds__(64) FA_K7_WAVES_ATTR void decode_frames_kernel(Deco
     constexpr int kTileG = kTileW / 4;
     constexpr int kTileSwz = 32 / kTileG;
     static_assert(NCH == 1 || (kTileW == 32 && !F32), "two-channel variant: 32-sample tiles, integer output");
-    __shared__ __attribute__((aligned(16))) uint32_t rings[kDecRingWords * kLaneStride];
-    __shared__ __attribute__((aligned(16))) int32_t tile[kTileW * kLaneStride];  // sample t of lane l at t*64 + (l ^ 8*(t>>2))
-    __shared__ float2 row_fg[F32 ? 64 : 1];
+    // one LDS object, so that the ring image starts at LDS address 0 (ring_words builds its addresses with an OR)
+    __shared__ __attribute__((aligned(16))) uint32_t lds_k7[kDecRingWords * kLaneStride + kTileW * kLaneStride + (F32 ? 128 : 0)];
+    uint32_t* const rings = lds_k7;
+    int32_t* const tile = reinterpret_cast<int32_t*>(lds_k7 + kDecRingWords * kLaneStride);  // sample t of lane l at t*64 + (l ^ 8*(t>>2))
+    float2* const row_fg = reinterpret_cast<float2*>(lds_k7 + kDecRingWords * kLaneStride + kTileW * kLaneStride);
     const int lane = threadIdx.x;
     const int64_t task = (int64_t)blockIdx.x * 64 + lane;
     const bool has_task = task < a.n_tasks;
     uint32_t* const ring = rings + lane;
+    const uint32_t lane4 = (uint32_t)(uintptr_t)(lds_u32*)ring;
+    if ((uint32_t)(uintptr_t)(lds_u32*)rings & (kRingAddrMask | 255u)) {  // (never: `rings` is the first LDS object of the kernel)
+        if (lane == 0) atomicOr(a.err, kErrDecodeInit);
+        return;
+    }
 
     // ---- per-lane task setup ----
     int64_t s = 0, f = 0, sl_first = 0, sl_last = 0, out_off = 0;
@@ -883,7 +902,7 @@ __global__ __launch_bounds__(64) FA_K7_WAVES_ATTR void decode_frames_kernel(Deco
             for (int i = 0; i < order; ++i) {
                 const double x = get_wide(bps);
                 if (i < kTileW) {
-                    tile[i * kLaneStride + (lane ^ ((i >> 2) * kTileSwz))] = (int32_t)((uint32_t)wrap32(x) << wasted);
+                    tile[i * kLaneStride + (lane ^ ((i >> 2) * kTileSwz))] = wrap32(x);  // (wasted bits are restored in flush_tile)
                     if constexpr (NCH == 2) hbw |= (x < 0.0) ? (1u << i) : 0u;
                 }
 #pragma unroll
@@ -990,6 +1009,9 @@ __global__ __launch_bounds__(64) FA_K7_WAVES_ATTR void decode_frames_kernel(Deco
     hi_min = __builtin_amdgcn_readfirstlane(hi_min);
     hi_max = __builtin_amdgcn_readfirstlane(hi_max);
     const bool all_al = __all(row_al);
+    // wasted bits are rare: the sample loop stores unshifted values and the tile flush restores the shift of each
+    // row's frame only when some lane of the wave has one (wave-uniform branch)
+    const bool any_wasted = __any(wasted != 0);
     // chunk `pend_ci` is requested one chunk-time before it is stored into the ring
     uint32_t pend_ci = next_chunk;
     Chunk pend = chunk_fetch(cbase, lim16, pend_ci);
@@ -1003,8 +1025,10 @@ __global__ __launch_bounds__(64) FA_K7_WAVES_ATTR void decode_frames_kernel(Deco
         }
     };
     uint32_t pw0, pw1, pw2;  // ring words of the current bit position
-    ring_words(ring, bitpos, pw0, pw1, pw2);
-    int kf = (escw < 0) ? k : 64;  // fast-path key: z + kf < 32  <=>  plain Rice code of at most 32 bits
+    ring_words(lane4, bitpos, pw0, pw1, pw2);
+    // fast-path key: a plain Rice code of at most 32 bits  <=>  zr < zlim (unsigned; v_ffbh_u32 gives 0xffffffff for an
+    // empty window, which no bound admits; escaped partitions, finished frames and idle lanes carry the bound 0)
+    uint32_t zlim = (escw < 0) ? (uint32_t)(32 - k) : 0u;
 
     // one sample of every lane.  GUARD: lanes may be in warm-up or past their frame's end.
     // PART: a partition boundary may fall inside this macro step (decided once per step for the wave)
@@ -1015,7 +1039,7 @@ __global__ __launch_bounds__(64) FA_K7_WAVES_ATTR void decode_frames_kernel(Deco
         bool live = true;
         if constexpr (GUARD) {
             live = (i < bs) && (i >= order);
-            if (i >= bs) { escw = 0; kf = 64; pleft = 0x7fffffff; }  // frame finished: consume nothing more
+            if (i >= bs) { escw = 0; zlim = 0u; pleft = 0x7fffffff; }  // frame finished: consume nothing more
         }
         if (live) {
             // rare events are tested wave-wide first, so the common case carries no exec-mask code
@@ -1024,19 +1048,21 @@ __global__ __launch_bounds__(64) FA_K7_WAVES_ATTR void decode_frames_kernel(Deco
                     const ParamRet pr = slow_param(cbase, lim16, ring, bitpos, next_chunk, plen, esc);
                     k = (int)pr.k;
                     escw = (int)pr.escw;  // -1: plain Rice partition
-                    kf = (escw < 0) ? k : 64;
+                    zlim = (escw < 0) ? (uint32_t)(32 - k) : 0u;
                     bitpos = pr.bitpos;
                     next_chunk = pr.next_chunk;
                     pleft += ps;
                 }
-                ring_words(ring, bitpos, pw0, pw1, pw2);
+                ring_words(lane4, bitpos, pw0, pw1, pw2);
             }
             // window from the words prefetched at the end of the previous sample
             const uint32_t sh = (~(bitpos - 1)) & 31;  // 32 - off'
             const uint32_t A = __builtin_amdgcn_alignbit(pw0, pw1, sh);
             const uint32_t Bw = __builtin_amdgcn_alignbit(pw1, pw2, sh);
-            const int z = __clz((int)A);  // 32 when A == 0
-            const bool fastok = (z + kf < 32);
+            uint32_t zr;  // zeros before the stop bit; 0xffffffff when the window holds none (asm: __clz adds a v_min)
+            asm("v_ffbh_u32 %0, %1" : "=v"(zr) : "v"(A));
+            const int z = (int)zr;
+            const bool fastok = (zr < zlim);
             // fast path for every lane (harmless where it does not apply): z zeros, stop bit, k low bits
             const uint32_t X = __builtin_amdgcn_alignbit(A, Bw, (uint32_t)(31 - z) & 31);  // bits after the stop bit
             const uint32_t low = __builtin_amdgcn_ubfe(X, (uint32_t)((32 - k) & 31), (uint32_t)k);
@@ -1048,7 +1074,7 @@ __global__ __launch_bounds__(64) FA_K7_WAVES_ATTR void decode_frames_kernel(Deco
             const uint64_t okm = __ballot(fastok);
             if (__builtin_expect(okm != __builtin_amdgcn_read_exec(), 0)) {
                 if (!((okm >> lane) & 1ull)) {
-                    if (escw < 0 && z < 32 && ((nbp + 128u) >> kChunkShift) < next_chunk) {
+                    if (escw < 0 && zr < 32u && ((nbp + 128u) >> kChunkShift) < next_chunk) {
                         // a Rice code of 33..63 bits whose stop bit lies inside the window and whose
                         // successor's window is resident: r and nbp above are already right (the
                         // 32-bit limit of `fastok` only budgets the top-up, it is not a decoding limit)
@@ -1074,29 +1100,29 @@ __global__ __launch_bounds__(64) FA_K7_WAVES_ATTR void decode_frames_kernel(Deco
                         next_chunk = sr.next_chunk;
                         if (sr.bad) {  // stop consuming: the rest of this lane's frame is zero-width
                             atomicOr(a.err, kErrDecodeProcess);
-                            escw = 0; kf = 64; pleft = 0x7fffffff; r = 0; nbp = bitpos;
+                            escw = 0; zlim = 0u; pleft = 0x7fffffff; r = 0; nbp = bitpos;
                         }
                     }
                 }
             }
             bitpos = nbp;
-            ring_words(ring, bitpos, pw0, pw1, pw2);  // LDS latency hides behind the prediction below
+            ring_words(lane4, bitpos, pw0, pw1, pw2);  // LDS latency hides behind the prediction below
             if constexpr (PART) pleft--;
             // every term is an exact integer in double, so the order is free: the newest sample enters
             // last and the loop-carried chain is one fma + floor + add
-            double sum = 0.0;
+            // The residual seeds the chain: it is an integer, so floor(r + sum) = r + floor(sum), and every partial sum
+            // stays exact (a multiple of 2^-shift below 2^52 x 2^-shift), which saves the separate add.
+            double sum = (double)r;
+            if constexpr (NCH == 2) sum += radd;
 #pragma unroll
             for (int j = MO - 1; j >= 0; --j) sum = __builtin_fma(c[j], h[(u + MO - 1 - j) % MO], sum);
-            double xd = (double)r + fa_floor(sum);
-            if constexpr (NCH == 2) {
-                xd += radd;
-                hbw |= (xd < 0.0) ? (1u << (i & 31)) : 0u;
-            }
+            const double xd = fa_floor(sum);
+            if constexpr (NCH == 2) hbw |= (xd < 0.0) ? (1u << (i & 31)) : 0u;
             h[u % MO] = xd;
-            tile[u * kLaneStride + (lane ^ ((u >> 2) * kTileSwz))] = (int32_t)((uint32_t)wrap32(xd) << wasted);
+            tile[u * kLaneStride + (lane ^ ((u >> 2) * kTileSwz))] = wrap32(xd);
         } else if constexpr (GUARD) {
             // warm-up sample 16..31 (orders above 16): its value sits in the history
-            if (i < bs && i >= kTileW) tile[u * kLaneStride + (lane ^ ((u >> 2) * kTileSwz))] = (int32_t)((uint32_t)wrap32(h[u % MO]) << wasted);
+            if (i < bs && i >= kTileW) tile[u * kLaneStride + (lane ^ ((u >> 2) * kTileSwz))] = wrap32(h[u % MO]);
         }
     };
 
@@ -1118,8 +1144,9 @@ __global__ __launch_bounds__(64) FA_K7_WAVES_ATTR void decode_frames_kernel(Deco
                 const int cg = lane % kTileG;
                 const int cb = 4 * cg;
                 const int rsw = r ^ (cg * kTileSwz);
-                const int4 v = make_int4(tile[(cb + 0) * kLaneStride + rsw], tile[(cb + 1) * kLaneStride + rsw],
-                                         tile[(cb + 2) * kLaneStride + rsw], tile[(cb + 3) * kLaneStride + rsw]);
+                int4 v = make_int4(tile[(cb + 0) * kLaneStride + rsw], tile[(cb + 1) * kLaneStride + rsw],
+                                   tile[(cb + 2) * kLaneStride + rsw], tile[(cb + 3) * kLaneStride + rsw]);
+                if (__builtin_expect(any_wasted, 0)) v = shl4(v, __builtin_amdgcn_ds_bpermute(r << 2, wasted));
                 if constexpr (F32) {
                     const float2 fg = row_fg[r];
                     float4 o;
@@ -1141,8 +1168,9 @@ __global__ __launch_bounds__(64) FA_K7_WAVES_ATTR void decode_frames_kernel(Deco
             const int cg = lane % kTileG;
             const int cb = 4 * cg;
             const int rsw = r ^ (cg * kTileSwz);  // the writer's swizzle
-            const int4 v = make_int4(tile[(cb + 0) * kLaneStride + rsw], tile[(cb + 1) * kLaneStride + rsw], tile[(cb + 2) * kLaneStride + rsw],
-                                     tile[(cb + 3) * kLaneStride + rsw]);
+            int4 v = make_int4(tile[(cb + 0) * kLaneStride + rsw], tile[(cb + 1) * kLaneStride + rsw], tile[(cb + 2) * kLaneStride + rsw],
+                               tile[(cb + 3) * kLaneStride + rsw]);
+            if (__builtin_expect(any_wasted, 0)) v = shl4(v, __builtin_amdgcn_ds_bpermute(r << 2, wasted));
             const int2 rg = make_int2(__builtin_amdgcn_ds_bpermute(r << 2, lo), __builtin_amdgcn_ds_bpermute(r << 2, hi));
             const int si = tbase + cb;
             if (si + 3 >= rg.x && si < rg.y) {

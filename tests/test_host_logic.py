@@ -274,7 +274,8 @@ def test_hdf5_v1_layout_roundtrip(oracle):
 
 def test_zarr_v1_layout_roundtrip(oracle):
     """The Zarr layout is the HDF5 one; zarr-3 groups create arrays with create_array (zarr.py:236-241)."""
-    from flacarray_amd import hdf5 as Z  # (the Zarr layout is the HDF5 one: same functions)
+    from flacarray_amd import zarr as Z  # (the reference module name, zarr.py:145-447)
+    from flacarray_amd.zarr import read_array, write_array  # noqa: F401  (the names the reference exports)
     from tests.conftest import FakeZarr3Group, sinusoid_noise_i32
 
     x = sinusoid_noise_i32(4, 3000, seed=8)
