@@ -106,9 +106,9 @@ def lib():
     L.fa_encode_i32_device.restype = cint
     L.fa_encode_f32_device.argtypes = [vp, i64, i64, u32, vp, vp, i64, vp, i64, vp, vp, vp, vp, pi64, vp, vp]
     L.fa_encode_f32_device.restype = cint
-    L.fa_decode_i32_device.argtypes = [vp, i64, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, vp]
+    L.fa_decode_i32_device.argtypes = [vp, i64, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, vp, cint]
     L.fa_decode_i32_device.restype = cint
-    L.fa_decode_slices_i32_device.argtypes = [vp, i64, vp, vp, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.fa_decode_slices_i32_device.argtypes = [vp, i64, vp, vp, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, cint]
     L.fa_decode_slices_i32_device.restype = cint
     L.fa_float32_to_int32_device.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp]
     L.fa_float32_to_int32_device.restype = cint
@@ -118,7 +118,7 @@ def lib():
     L.fa_decode_index_create.restype = cint
     L.fa_decode_index_destroy.argtypes = [vp]
     L.fa_decode_index_destroy.restype = None
-    L.fa_decode_indexed.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.fa_decode_indexed.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, cint]
     L.fa_decode_indexed.restype = cint
     L.fa_set_decode_verify.argtypes = [cint]
     L.fa_set_decode_verify.restype = cint

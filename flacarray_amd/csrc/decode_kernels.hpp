@@ -533,6 +533,15 @@ __device__ __forceinline__ void static_for(F&& f) {
 #ifndef FA_TILE_W
 #define FA_TILE_W 32
 #endif
+#ifndef FA_K7_SEED
+#define FA_K7_SEED 0
+#endif
+#ifndef FA_K7_NT
+#define FA_K7_NT 1  // whole-tile stores bypass the caches (streaming output): -1.5 % in the same-box A/B (r03i)
+#endif
+#ifndef FA_K7_X
+#define FA_K7_X 0  // timing experiments only (results are wrong): 1 = no prediction, 2 = no global stores, 4 = no tile write
+#endif
 constexpr int kTileW = FA_TILE_W;                // samples per lane between two cooperative stores
 constexpr int kTileG = kTileW / 4;               // 16-byte groups per row
 constexpr int kTileSwz = 32 / kTileG;            // XOR swizzle step: 32 lanes of a store pass hit 32 banks
@@ -569,6 +578,10 @@ __device__ __forceinline__ void ring_load_chunk(const uint8_t* cbase, const uint
 struct Chunk {
     uint4 d[kChunkBytes / 16];
 };
+// (The four loads are conditional loads into zero-initialised registers, which makes the compiler wait for the
+// previous load before each of them.  That serialisation is worth keeping: the four pieces share a cache line, the
+// first load brings it into L1 and the other three hit; issued back to back -- unconditional loads from a clamped
+// address -- all four miss and K7 is 12 % slower, profiles/r03_k7_experiments.md.)
 __device__ __forceinline__ Chunk chunk_fetch(const uint8_t* cbase, const uint8_t* lim16, uint32_t ci) {
     const uint8_t* q = cbase + (size_t)ci * kChunkBytes;
     Chunk c;
@@ -1108,17 +1121,34 @@ __global__ __launch_bounds__(64) FA_K7_WAVES_ATTR void decode_frames_kernel(Deco
             bitpos = nbp;
             ring_words(lane4, bitpos, pw0, pw1, pw2);  // LDS latency hides behind the prediction below
             if constexpr (PART) pleft--;
-            // every term is an exact integer in double, so the order is free: the newest sample enters
-            // last and the loop-carried chain is one fma + floor + add
-            // The residual seeds the chain: it is an integer, so floor(r + sum) = r + floor(sum), and every partial sum
-            // stays exact (a multiple of 2^-shift below 2^52 x 2^-shift), which saves the separate add.
+            // every term is an exact integer in double, so the order is free: the newest sample enters last and the
+            // loop-carried chain is one fma + floor + add
+#if FA_K7_SEED  // experiment: the residual seeds the chain (floor(r + sum) = r + floor(sum), every partial sum exact): one add
+                // less, but the eight dependent FMAs then start behind the bit decode instead of beside it
             double sum = (double)r;
             if constexpr (NCH == 2) sum += radd;
 #pragma unroll
             for (int j = MO - 1; j >= 0; --j) sum = __builtin_fma(c[j], h[(u + MO - 1 - j) % MO], sum);
             const double xd = fa_floor(sum);
             if constexpr (NCH == 2) hbw |= (xd < 0.0) ? (1u << (i & 31)) : 0u;
+#else
+            double sum = 0.0;
+#if !(FA_K7_X & 1)
+#pragma unroll
+            for (int j = MO - 1; j >= 0; --j) sum = __builtin_fma(c[j], h[(u + MO - 1 - j) % MO], sum);
+#else
+            sum = h[(u + MO - 1) % MO];
+#endif
+            double xd = (double)r + fa_floor(sum);
+            if constexpr (NCH == 2) {
+                xd += radd;
+                hbw |= (xd < 0.0) ? (1u << (i & 31)) : 0u;
+            }
+#endif
             h[u % MO] = xd;
+#if (FA_K7_X & 4)
+            if (u == 0)
+#endif
             tile[u * kLaneStride + (lane ^ ((u >> 2) * kTileSwz))] = wrap32(xd);
         } else if constexpr (GUARD) {
             // warm-up sample 16..31 (orders above 16): its value sits in the history
@@ -1154,9 +1184,28 @@ __global__ __launch_bounds__(64) FA_K7_WAVES_ATTR void decode_frames_kernel(Deco
                     o.y = __fadd_rn(fg.x, __fmul_rn(fg.y, (float)v.y));
                     o.z = __fadd_rn(fg.x, __fmul_rn(fg.y, (float)v.z));
                     o.w = __fadd_rn(fg.x, __fmul_rn(fg.y, (float)v.w));
+#if FA_K7_NT
+                    {
+                        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+                        f32x4_t vv; vv.x = o.x; vv.y = o.y; vv.z = o.z; vv.w = o.w;
+                        __builtin_nontemporal_store(vv, reinterpret_cast<f32x4_t*>(a.out_f32 + rout[it] + tbase + cb));
+                    }
+#else
                     *reinterpret_cast<float4*>(a.out_f32 + rout[it] + tbase + cb) = o;
+#endif
                 } else {
+#if (FA_K7_X & 2)
+                    if (v.x == 0x12345678)
+#endif
+#if FA_K7_NT
+                    {
+                        typedef int i32x4_t __attribute__((ext_vector_type(4)));
+                        i32x4_t vv; vv.x = v.x; vv.y = v.y; vv.z = v.z; vv.w = v.w;
+                        __builtin_nontemporal_store(vv, reinterpret_cast<i32x4_t*>(a.out_i32 + rout[it] + tbase + cb));
+                    }
+#else
                     *reinterpret_cast<int4*>(a.out_i32 + rout[it] + tbase + cb) = v;
+#endif
                 }
             }
             __builtin_amdgcn_wave_barrier();

@@ -326,8 +326,9 @@ void make_fused_plan(int64_t n_stream, int64_t stream_size, uint32_t level, Fuse
 
 
 // optional CRC-16 check of every frame the decode just read (verify_kernels.hpp); h_err receives the refreshed flags
-int run_verify(const DecodeArgs& a, int* d_err, int* h_err, hipStream_t st) {
-    if (!g_verify) return FA_ERROR_NONE;
+// verify: 1 = check, 0 = do not, negative = the process default (fa_set_decode_verify)
+int run_verify(const DecodeArgs& a, int* d_err, int* h_err, hipStream_t st, int verify) {
+    if (!(verify < 0 ? g_verify.load() : verify != 0)) return FA_ERROR_NONE;
     const uint16_t* tab = nullptr;
     int rc = get_crc_tab_fused(&tab);
     if (rc) return rc;
@@ -361,7 +362,7 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
                        const int64_t* out_offset, int32_t* d_out_i32, float* d_out_f32, const float* d_offsets,
                        const float* d_gains, hipStream_t st, int nch = 1, int64_t* d_out_i64 = nullptr, double* d_out_f64 = nullptr,
                        const double* d_offsets64 = nullptr, const double* d_gains64 = nullptr, DecodeIndex* idx = nullptr,
-                       bool build_only = false) {
+                       bool build_only = false, int verify = -1) {
     int rc = FA_ERROR_NONE;
     int h_err[4] = {0, 0, 0, 0};
     StreamMeta* d_meta = nullptr;
@@ -542,7 +543,7 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
         FA_HIP_TRY(hipMemcpyAsync(h_err, d_err, 16, hipMemcpyDeviceToHost, st));
         FA_HIP_TRY(hipStreamSynchronize(st));
         FA_HIP_TRY(hipGetLastError());
-        if ((rc = run_verify(a, d_err, h_err, st))) return rc;
+        if ((rc = run_verify(a, d_err, h_err, st, verify))) return rc;
         return h_err[0];
     }
 #endif
@@ -554,7 +555,7 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
     prof_end(4, st);
     FA_HIP_TRY(hipMemcpyAsync(h_err, d_err, 16, hipMemcpyDeviceToHost, st));
     FA_HIP_TRY(hipStreamSynchronize(st));
-    if ((rc = run_verify(a, d_err, h_err, st))) return rc;
+    if ((rc = run_verify(a, d_err, h_err, st, verify))) return rc;
     return h_err[0] | (h_err[1] ? FA_ERROR_DECODE_PROCESS : 0);
 #else
     if (f32) hipLaunchKernelGGL((decode_frames_kernel<8, -1, true, 1>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
@@ -576,7 +577,7 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
         FA_HIP_TRY(hipStreamSynchronize(st));
     }
     FA_HIP_TRY(hipGetLastError());
-    if ((rc = run_verify(a, d_err, h_err, st))) return rc;
+    if ((rc = run_verify(a, d_err, h_err, st, verify))) return rc;
     return h_err[0];
 #endif
 }
@@ -933,6 +934,19 @@ static int fused_encode_run(const void* d_data, bool f32, const float* d_quanta,
     launch_fused_encode(st, a, f32);
     prof_end(0, st);
     int64_t* d_total = reinterpret_cast<int64_t*>(ws + pl.off_total);
+    int h_err = 0;
+    {
+        // A frame that was dropped (no offset in time, or an offset outside the buffer) leaves frame_abs / off_pub of
+        // itself -- and, after a scanner time-out, of every frame behind it -- unwritten: the kernels below would
+        // turn those into addresses.  They run only after the error word has come back clean (one stream
+        // synchronisation, ~20 us against a 15 ms kernel).
+        FA_HIP_TRY(hipMemcpyAsync(&h_err, a.err, 4, hipMemcpyDeviceToHost, st));
+        FA_HIP_TRY(hipStreamSynchronize(st));
+        if (h_err) {
+            std::fprintf(stderr, "flacarray_hip: single-pass encode failed (flags %d: 1 = offset outside the buffer, 2 = a frame timed out waiting for its offset, 4 = the scanner timed out)\n", h_err);
+            return FA_ERROR_ENCODE_PROCESS;
+        }
+    }
     if (tails) {
         // every frame has its offset now: move the short frames from their slots (byte-shifted copy + CRC-16, K5)
         uint32_t* tb = reinterpret_cast<uint32_t*>(ws + pl.off_tbytes);
@@ -948,7 +962,7 @@ static int fused_encode_run(const void* d_data, bool f32, const float* d_quanta,
     }
     launch_fused_finish(st, d_bytes, a.frame_abs, a.frame_bytes, n_stream, pl.nf, stream_size, (int32_t)pl.tail_bs, pl.hb, d_starts, d_nbytes, d_total);
     prof_end(3, st);
-    int h_err = 0, h_nan = 0;
+    int h_nan = 0;
     FA_HIP_TRY(hipMemcpyAsync(&h_err, a.err, 4, hipMemcpyDeviceToHost, st));
     FA_HIP_TRY(hipMemcpyAsync(&h_nan, d_nanflag, 4, hipMemcpyDeviceToHost, st));
     FA_HIP_TRY(hipMemcpyAsync(h_total_bytes, d_total, 8, hipMemcpyDeviceToHost, st));
@@ -999,7 +1013,7 @@ int fa_encode_f32_device(const float* d_data, int64_t n_stream, int64_t stream_s
 int fa_decode_i32_device(const unsigned char* d_bytes, int64_t n_bytes, const int64_t* d_starts,
                          const int64_t* d_nbytes, int64_t n_stream, int64_t stream_size, int64_t first_sample,
                          int64_t last_sample, int32_t* d_out_i32, float* d_out_f32, const float* d_offsets,
-                         const float* d_gains, void* stream) {
+                         const float* d_gains, void* stream, int verify) {
     FA_API_LOCK;
     if (n_stream <= 0) return FA_ERROR_ZERO_NSTREAM;
     if (stream_size <= 0) return FA_ERROR_DECODE_STREAMSIZE;
@@ -1010,14 +1024,14 @@ int fa_decode_i32_device(const unsigned char* d_bytes, int64_t n_bytes, const in
     if (rc) return rc;
     return decode_device_impl(d_bytes, n_bytes, d_starts, d_nbytes, n_stream, stream_size, first_decode, n_decode, -1, nullptr,
                               nullptr, nullptr, nullptr, d_out_i32, d_out_f32, d_offsets, d_gains,
-                              reinterpret_cast<hipStream_t>(stream));
+                              reinterpret_cast<hipStream_t>(stream), 1, nullptr, nullptr, nullptr, nullptr, nullptr, false, verify);
 }
 
 int fa_decode_slices_i32_device(const unsigned char* d_bytes, int64_t n_bytes, const int64_t* d_starts,
                                 const int64_t* d_nbytes, int64_t n_stream, int64_t stream_size, int64_t n_slices,
                                 const int64_t* slice_stream, const int64_t* slice_first, const int64_t* slice_count,
                                 const int64_t* out_offset, int32_t* d_out_i32, float* d_out_f32,
-                                const float* d_offsets, const float* d_gains, void* stream) {
+                                const float* d_offsets, const float* d_gains, void* stream, int verify) {
     FA_API_LOCK;
     if (n_stream <= 0) return FA_ERROR_ZERO_NSTREAM;
     if (stream_size <= 0) return FA_ERROR_DECODE_STREAMSIZE;
@@ -1026,7 +1040,7 @@ int fa_decode_slices_i32_device(const unsigned char* d_bytes, int64_t n_bytes, c
     if (d_out_f32 && (!d_offsets || !d_gains)) return FA_ERROR_CONVERT_TYPE;
     return decode_device_impl(d_bytes, n_bytes, d_starts, d_nbytes, n_stream, stream_size, 0, 0, n_slices, slice_stream,
                               slice_first, slice_count, out_offset, d_out_i32, d_out_f32, d_offsets, d_gains,
-                              reinterpret_cast<hipStream_t>(stream));
+                              reinterpret_cast<hipStream_t>(stream), 1, nullptr, nullptr, nullptr, nullptr, nullptr, false, verify);
 }
 
 int fa_decode_index_create(const unsigned char* d_bytes, int64_t n_bytes, const int64_t* d_starts, const int64_t* d_nbytes,
@@ -1056,6 +1070,12 @@ int fa_decode_index_create(const unsigned char* d_bytes, int64_t n_bytes, const 
 void fa_decode_index_destroy(void* index) {
     DecodeIndex* ix = reinterpret_cast<DecodeIndex*>(index);
     if (!ix) return;
+    // the index belongs to the device it was created on: free it there, whatever the caller's current device is
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    const bool hop = (ix->device >= 0 && cur != ix->device);
+    if (hop) (void)hipSetDevice(ix->device);
+    struct Back { bool on; int dev; ~Back() { if (on) (void)hipSetDevice(dev); } } back{hop, cur};
     FA_API_LOCK_OR(return);
     if (ix->meta) (void)hipFree(ix->meta);
     if (ix->ftab) (void)hipFree(ix->ftab);
@@ -1065,10 +1085,14 @@ void fa_decode_index_destroy(void* index) {
 
 int fa_decode_indexed(void* index, int64_t first_sample, int64_t last_sample, int64_t n_slices, const int64_t* slice_stream,
                       const int64_t* slice_first, const int64_t* slice_count, const int64_t* out_offset, void* d_out_int,
-                      void* d_out_float, const void* d_offsets, const void* d_gains, void* stream) {
+                      void* d_out_float, const void* d_offsets, const void* d_gains, void* stream, int verify) {
     FA_API_LOCK;
     DecodeIndex* ix = reinterpret_cast<DecodeIndex*>(index);
     if (!ix) return FA_ERROR_DECODE_INIT;
+    {   // an index is used on the device that holds it (its tables, the store and this call's lock are that device's)
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != ix->device) return FA_ERROR_DEVICE;
+    }
     if ((d_out_int == nullptr) == (d_out_float == nullptr)) return FA_ERROR_CONVERT_TYPE;
     if (d_out_float && (!d_offsets || !d_gains)) return FA_ERROR_CONVERT_TYPE;
     int64_t first_decode = 0, n_decode = 0;
@@ -1083,17 +1107,17 @@ int fa_decode_indexed(void* index, int64_t first_sample, int64_t last_sample, in
         return decode_device_impl(nullptr, 0, nullptr, nullptr, 0, 0, first_decode, n_decode, n_slices, slice_stream, slice_first, slice_count,
                                   out_offset, reinterpret_cast<int32_t*>(d_out_int), reinterpret_cast<float*>(d_out_float),
                                   reinterpret_cast<const float*>(d_offsets), reinterpret_cast<const float*>(d_gains), st, 1, nullptr, nullptr,
-                                  nullptr, nullptr, ix, false);
+                                  nullptr, nullptr, ix, false, verify);
     return decode_device_impl(nullptr, 0, nullptr, nullptr, 0, 0, first_decode, n_decode, n_slices, slice_stream, slice_first, slice_count,
                               out_offset, nullptr, nullptr, nullptr, nullptr, st, 2, reinterpret_cast<int64_t*>(d_out_int),
                               reinterpret_cast<double*>(d_out_float), reinterpret_cast<const double*>(d_offsets),
-                              reinterpret_cast<const double*>(d_gains), ix, false);
+                              reinterpret_cast<const double*>(d_gains), ix, false, verify);
 }
 
 int fa_decode_i64_device(const unsigned char* d_bytes, int64_t n_bytes, const int64_t* d_starts,
                          const int64_t* d_nbytes, int64_t n_stream, int64_t stream_size, int64_t first_sample,
                          int64_t last_sample, int64_t* d_out_i64, double* d_out_f64, const double* d_offsets,
-                         const double* d_gains, void* stream) {
+                         const double* d_gains, void* stream, int verify) {
     FA_API_LOCK;
     if (n_stream <= 0) return FA_ERROR_ZERO_NSTREAM;
     if (stream_size <= 0) return FA_ERROR_DECODE_STREAMSIZE;
@@ -1104,14 +1128,14 @@ int fa_decode_i64_device(const unsigned char* d_bytes, int64_t n_bytes, const in
     if (rc) return rc;
     return decode_device_impl(d_bytes, n_bytes, d_starts, d_nbytes, n_stream, stream_size, first_decode, n_decode, -1, nullptr,
                               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<hipStream_t>(stream), 2,
-                              d_out_i64, d_out_f64, d_offsets, d_gains);
+                              d_out_i64, d_out_f64, d_offsets, d_gains, nullptr, false, verify);
 }
 
 int fa_decode_slices_i64_device(const unsigned char* d_bytes, int64_t n_bytes, const int64_t* d_starts,
                                 const int64_t* d_nbytes, int64_t n_stream, int64_t stream_size, int64_t n_slices,
                                 const int64_t* slice_stream, const int64_t* slice_first, const int64_t* slice_count,
                                 const int64_t* out_offset, int64_t* d_out_i64, double* d_out_f64,
-                                const double* d_offsets, const double* d_gains, void* stream) {
+                                const double* d_offsets, const double* d_gains, void* stream, int verify) {
     FA_API_LOCK;
     if (n_stream <= 0) return FA_ERROR_ZERO_NSTREAM;
     if (stream_size <= 0) return FA_ERROR_DECODE_STREAMSIZE;
@@ -1120,7 +1144,7 @@ int fa_decode_slices_i64_device(const unsigned char* d_bytes, int64_t n_bytes, c
     if (d_out_f64 && (!d_offsets || !d_gains)) return FA_ERROR_CONVERT_TYPE;
     return decode_device_impl(d_bytes, n_bytes, d_starts, d_nbytes, n_stream, stream_size, 0, 0, n_slices, slice_stream,
                               slice_first, slice_count, out_offset, nullptr, nullptr, nullptr, nullptr,
-                              reinterpret_cast<hipStream_t>(stream), 2, d_out_i64, d_out_f64, d_offsets, d_gains);
+                              reinterpret_cast<hipStream_t>(stream), 2, d_out_i64, d_out_f64, d_offsets, d_gains, nullptr, false, verify);
 }
 
 int fa_float32_to_int32_device(const float* d_input, int64_t n_stream, int64_t stream_size, const float* d_quanta,
@@ -1310,6 +1334,11 @@ static int decode_host(const unsigned char* bytes, const int64_t* starts, const 
     if (chunk < 1) chunk = 1;
     if (chunk > n_stream) chunk = n_stream;
     int err = FA_ERROR_NONE;
+    // The reference's decoder always checks the frame CRC-16 (libFLAC reports a mismatch through the error callback,
+    // decompress.c:104-121); on this entry point the check is on unless FLACARRAY_HIP_HOST_VERIFY=0 -- the bytes
+    // crossed PCIe anyway, one more read of them in HBM is in the noise.
+    const char* hv = std::getenv("FLACARRAY_HIP_HOST_VERIFY");
+    const int host_verify = (hv && hv[0] == '0') ? 0 : 1;
     std::vector<int64_t> st_rel;
     for (int64_t s0 = 0; s0 < n_stream && !err; s0 += chunk) {
         const int64_t ns = (n_stream - s0 < chunk) ? (n_stream - s0) : chunk;
@@ -1336,11 +1365,11 @@ static int decode_host(const unsigned char* bytes, const int64_t* starts, const 
         if (nch == 1)
             err = decode_device_impl(reinterpret_cast<const unsigned char*>(d_blob), hi - lo, d_starts, d_nb, ns, stream_size,
                                      first_decode, n_decode, -1, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<int32_t*>(d_out),
-                                     nullptr, nullptr, nullptr, nullptr);
+                                     nullptr, nullptr, nullptr, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, false, host_verify);
         else
             err = decode_device_impl(reinterpret_cast<const unsigned char*>(d_blob), hi - lo, d_starts, d_nb, ns, stream_size,
                                      first_decode, n_decode, -1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                     nullptr, 2, reinterpret_cast<int64_t*>(d_out), nullptr, nullptr, nullptr);
+                                     nullptr, 2, reinterpret_cast<int64_t*>(d_out), nullptr, nullptr, nullptr, nullptr, false, host_verify);
         if (err) break;
         if (hipMemcpy(data + (size_t)s0 * (size_t)n_decode * esz, d_out, (size_t)ns * (size_t)n_decode * esz, hipMemcpyDeviceToHost) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
     }

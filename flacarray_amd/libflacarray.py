@@ -351,11 +351,16 @@ def encode_flac_device(data, level=5, workspace=None, return_info=False, compact
 
 
 def set_decode_verify(on):
-    """Process-wide switch of the decoder's integrity pass: when on, every decode call re-computes the CRC-16 of each
-    frame it read and raises ("Decoding failed, return code = 16384", ERROR_DECODE_PROCESS) on a mismatch -- the
-    condition libFLAC reports through the error callback the reference prints (decompress.c:104-121).  Returns the
-    previous setting.  Off by default: the pass re-reads the compressed bytes."""
+    """Process-wide DEFAULT of the decoder's integrity pass, used by device decode calls whose `verify` argument is
+    None: when on, the call re-computes the CRC-16 of each frame it read and raises ("Decoding failed, return code =
+    16384", ERROR_DECODE_PROCESS) on a mismatch -- the condition libFLAC reports through the error callback the
+    reference prints (decompress.c:104-121).  Returns the previous setting.  Initially off for device-resident stores
+    (the pass re-reads the compressed bytes); the host-pointer path behind `decode_flac` always checks."""
     return bool(_lib.lib().fa_set_decode_verify(1 if on else 0))
+
+
+def _verify_arg(verify):
+    return -1 if verify is None else (1 if verify else 0)
 
 
 def encode_flac_device_f32(data, quanta=None, level=5, workspace=None, compact=False):
@@ -435,11 +440,13 @@ def _device_regroup(errcode, out, compressed, starts, nbytes, stream_size, first
 
 
 def decode_flac_device(compressed, starts, nbytes, stream_size, first_sample=-1, last_sample=-1, offsets=None, gains=None,
-                       is_int64=False):
+                       is_int64=False, verify=None):
     """Decode device-resident streams into an int32 tensor (or float32 when offsets/gains are
     given: the int->float restore of utils.c:350-368 is fused into the store).  is_int64:
-    two-channel streams -> int64 (or float64 with float64 offsets/gains, utils.c:329-348)."""
+    two-channel streams -> int64 (or float64 with float64 offsets/gains, utils.c:329-348).
+    verify: True / False = check every frame's CRC-16 or not; None = the default of set_decode_verify."""
     torch = _torch()
+    vfy = _verify_arg(verify)
     if compressed.dtype != torch.uint8:
         raise RuntimeError("Compressed data should be of type uint8")
     if starts.dtype != torch.int64:
@@ -471,7 +478,7 @@ def decode_flac_device(compressed, starts, nbytes, stream_size, first_sample=-1,
                 out = torch.empty(shape, dtype=torch.int64, device=dev)
                 errcode = L.fa_decode_i64_device(
                     _dp(compressed), compressed.numel(), _dp(starts), _dp(nbytes), n_stream, stream_size, first_sample,
-                    last_sample, _dp(out), None, None, None, _stream_ptr(),
+                    last_sample, _dp(out), None, None, None, _stream_ptr(), vfy,
                 )
             else:
                 out = torch.empty(shape, dtype=torch.float64, device=dev)
@@ -479,7 +486,7 @@ def decode_flac_device(compressed, starts, nbytes, stream_size, first_sample=-1,
                 gains = gains.to(device=dev, dtype=torch.float64).contiguous()
                 errcode = L.fa_decode_i64_device(
                     _dp(compressed), compressed.numel(), _dp(starts), _dp(nbytes), n_stream, stream_size, first_sample,
-                    last_sample, None, _dp(out), _dp(offsets), _dp(gains), _stream_ptr(),
+                    last_sample, None, _dp(out), _dp(offsets), _dp(gains), _stream_ptr(), vfy,
                 )
         if errcode != 0:
             return _device_regroup(errcode, out, compressed, starts, nbytes, stream_size, first_sample, last_sample, offsets, gains, True)
@@ -489,7 +496,7 @@ def decode_flac_device(compressed, starts, nbytes, stream_size, first_sample=-1,
             out = torch.empty(shape, dtype=torch.int32, device=dev)
             errcode = L.fa_decode_i32_device(
                 _dp(compressed), compressed.numel(), _dp(starts), _dp(nbytes), n_stream, stream_size, first_sample, last_sample,
-                _dp(out), None, None, None, _stream_ptr(),
+                _dp(out), None, None, None, _stream_ptr(), vfy,
             )
         else:
             out = torch.empty(shape, dtype=torch.float32, device=dev)
@@ -497,7 +504,7 @@ def decode_flac_device(compressed, starts, nbytes, stream_size, first_sample=-1,
             gains = gains.to(device=dev, dtype=torch.float32).contiguous()
             errcode = L.fa_decode_i32_device(
                 _dp(compressed), compressed.numel(), _dp(starts), _dp(nbytes), n_stream, stream_size, first_sample, last_sample,
-                None, _dp(out), _dp(offsets), _dp(gains), _stream_ptr(),
+                None, _dp(out), _dp(offsets), _dp(gains), _stream_ptr(), vfy,
             )
     if errcode != 0:
         return _device_regroup(errcode, out, compressed, starts, nbytes, stream_size, first_sample, last_sample, offsets, gains, False)
@@ -505,7 +512,7 @@ def decode_flac_device(compressed, starts, nbytes, stream_size, first_sample=-1,
 
 
 def decode_slices_device(compressed, starts, nbytes, stream_size, slice_stream, slice_first, slice_count, offsets=None, gains=None,
-                         is_int64=False):
+                         is_int64=False, verify=None):
     """Batched random access: slice i = samples [first[i], first[i]+count[i]) of (flat) stream
     slice_stream[i].  Returns (flat output tensor, int64 numpy array of output offsets).  The
     reference needs one decode call per slice (decompress.py:42-48)."""
@@ -534,7 +541,7 @@ def decode_slices_device(compressed, starts, nbytes, stream_size, slice_stream, 
             ctypes.c_void_p(slice_stream.ctypes.data), ctypes.c_void_p(slice_first.ctypes.data),
             ctypes.c_void_p(slice_count.ctypes.data), ctypes.c_void_p(out_off.ctypes.data),
             None if f32 else _dp(out), _dp(out) if f32 else None, _dp(soff) if f32 else None, _dp(sgain) if f32 else None,
-            _stream_ptr(),
+            _stream_ptr(), _verify_arg(verify),
         )
     if errcode != 0:
         raise RuntimeError(f"Decoding failed, return code = {errcode}")
@@ -588,7 +595,7 @@ class DeviceDecodeIndex:
         ft, it = (torch.float64, torch.int64) if self.is_int64 else (torch.float32, torch.int32)
         return ft if to_float else it, ft
 
-    def decode(self, first_sample=-1, last_sample=-1, offsets=None, gains=None):
+    def decode(self, first_sample=-1, last_sample=-1, offsets=None, gains=None, verify=None):
         """[first_sample, last_sample) (or everything) of ALL streams -> tensor [n_stream, n_decode]."""
         torch = _torch()
         n_decode = self.stream_size
@@ -608,13 +615,13 @@ class DeviceDecodeIndex:
         with torch.cuda.device(self.device):
             errcode = self._L.fa_decode_indexed(
                 self._h, first_sample, last_sample, -1, None, None, None, None, None if offsets is not None else _dp(out),
-                _dp(out) if offsets is not None else None, _dp(offsets), _dp(gains), _stream_ptr(),
+                _dp(out) if offsets is not None else None, _dp(offsets), _dp(gains), _stream_ptr(), _verify_arg(verify),
             )
         if errcode != 0:
             raise RuntimeError(f"Decoding failed, return code = {errcode}")
         return out
 
-    def decode_slices(self, slice_stream, slice_first, slice_count, offsets=None, gains=None):
+    def decode_slices(self, slice_stream, slice_first, slice_count, offsets=None, gains=None, verify=None):
         """Batched random access (see decode_slices_device): returns (flat tensor, int64 numpy array of offsets)."""
         torch = _torch()
         slice_stream = np.ascontiguousarray(slice_stream, dtype=np.int64)
@@ -636,7 +643,7 @@ class DeviceDecodeIndex:
                 self._h, -1, -1, n, ctypes.c_void_p(slice_stream.ctypes.data), ctypes.c_void_p(slice_first.ctypes.data),
                 ctypes.c_void_p(slice_count.ctypes.data), ctypes.c_void_p(out_off.ctypes.data),
                 None if offsets is not None else _dp(out), _dp(out) if offsets is not None else None, _dp(offsets), _dp(gains),
-                _stream_ptr(),
+                _stream_ptr(), _verify_arg(verify),
             )
         if errcode != 0:
             raise RuntimeError(f"Decoding failed, return code = {errcode}")

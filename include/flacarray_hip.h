@@ -144,18 +144,18 @@ int fa_encode_i64_device_finish(int64_t n_stream, int64_t stream_size, uint32_t 
 /* Decode [first_sample,last_sample) (or everything when either is negative) of n_stream
  * streams.  Exactly one of d_out_i32 / d_out_f32 is non-NULL; with d_out_f32 the int32 ->
  * float32 restore (utils.c:350-368) is fused into the store and d_offsets/d_gains[n_stream]
- * are required.  Returns the OR of the error bits (synchronises the stream). */
+ * are required.  verify: see fa_set_decode_verify.  Returns the OR of the error bits (synchronises the stream). */
 int fa_decode_i32_device(const unsigned char* d_bytes, int64_t n_bytes, const int64_t* d_starts,
                          const int64_t* d_nbytes, int64_t n_stream, int64_t stream_size, int64_t first_sample,
                          int64_t last_sample, int32_t* d_out_i32, float* d_out_f32, const float* d_offsets,
-                         const float* d_gains, void* stream);
+                         const float* d_gains, void* stream, int verify);
 
 /* The same for two-channel (int64 / float64) streams; with d_out_f64 the int64 -> float64 restore
  * (int64_to_float64, utils.c:329-348) is fused into the final pass. */
 int fa_decode_i64_device(const unsigned char* d_bytes, int64_t n_bytes, const int64_t* d_starts,
                          const int64_t* d_nbytes, int64_t n_stream, int64_t stream_size, int64_t first_sample,
                          int64_t last_sample, int64_t* d_out_i64, double* d_out_f64, const double* d_offsets,
-                         const double* d_gains, void* stream);
+                         const double* d_gains, void* stream, int verify);
 
 /* A decode index: the stream metadata and the byte offset of every frame of one store, computed once (K6) and kept in
  * device memory, for many reads of the same store -- the reference's usage pattern is one decode call per key
@@ -169,12 +169,13 @@ int fa_decode_index_create(const unsigned char* d_bytes, int64_t n_bytes, const 
 void fa_decode_index_destroy(void* index);
 int fa_decode_indexed(void* index, int64_t first_sample, int64_t last_sample, int64_t n_slices, const int64_t* slice_stream,
                       const int64_t* slice_first, const int64_t* slice_count, const int64_t* out_offset, void* d_out_int,
-                      void* d_out_float, const void* d_offsets, const void* d_gains, void* stream);
+                      void* d_out_float, const void* d_offsets, const void* d_gains, void* stream, int verify);
 
-/* Integrity check of the decoder (process-wide switch, returns the previous setting; default off).  When on, every
- * decode call re-computes the CRC-16 of each frame it read and reports a mismatch as FA_ERROR_DECODE_PROCESS -- what
- * libFLAC reports through the error callback the reference prints (decompress.c:104-121).  The header CRC-8 of every
- * frame is always checked. */
+/* Integrity check of the decoder.  Every device decode entry point takes `verify`: 1 = re-compute the CRC-16 of each
+ * frame the call read and report a mismatch as FA_ERROR_DECODE_PROCESS -- what libFLAC reports through the error
+ * callback the reference prints (decompress.c:104-121) --, 0 = do not, negative = the process-wide default set here
+ * (returns the previous setting; initially off).  The host-pointer decode_i32 / decode_i64 always check (libFLAC does;
+ * FLACARRAY_HIP_HOST_VERIFY=0 turns that off).  The header CRC-8 of every frame is checked in all cases. */
 int fa_set_decode_verify(int on);
 
 /* Batched random access: slice i is samples [first[i], first[i]+count[i]) of stream
@@ -185,13 +186,13 @@ int fa_decode_slices_i32_device(const unsigned char* d_bytes, int64_t n_bytes, c
                                 const int64_t* d_nbytes, int64_t n_stream, int64_t stream_size, int64_t n_slices,
                                 const int64_t* slice_stream, const int64_t* slice_first, const int64_t* slice_count,
                                 const int64_t* out_offset, int32_t* d_out_i32, float* d_out_f32,
-                                const float* d_offsets, const float* d_gains, void* stream);
+                                const float* d_offsets, const float* d_gains, void* stream, int verify);
 
 int fa_decode_slices_i64_device(const unsigned char* d_bytes, int64_t n_bytes, const int64_t* d_starts,
                                 const int64_t* d_nbytes, int64_t n_stream, int64_t stream_size, int64_t n_slices,
                                 const int64_t* slice_stream, const int64_t* slice_first, const int64_t* slice_count,
                                 const int64_t* out_offset, int64_t* d_out_i64, double* d_out_f64,
-                                const double* d_offsets, const double* d_gains, void* stream);
+                                const double* d_offsets, const double* d_gains, void* stream, int verify);
 
 /* float32 -> int32 quantisation on device; d_quanta may be NULL.  Returns FA_ERROR_NAN_INPUT
  * if any input is NaN (outputs are then unspecified). */

@@ -252,6 +252,23 @@ def test_frame_crc16_verification(fa, oracle):
             fa.decode_flac(bad, st, nb, 20000)
     finally:
         assert fa.set_decode_verify(False) is True
+    # per call: the argument wins over the process default (now off); the host-pointer ABI always checks, as libFLAC does
+    with pytest.raises(RuntimeError, match="Decoding failed"):
+        fa.decode_flac_device(*d(bad), 20000, verify=True)
+    assert not np.array_equal(fa.decode_flac_device(*d(bad), 20000, verify=False).cpu().numpy(), x)
+    with pytest.raises(RuntimeError, match="Decoding failed"):
+        fa.decode_flac(bad, st, nb, 20000)
+    ix = fa.DeviceDecodeIndex(*d(bad), 20000)
+    try:
+        with pytest.raises(RuntimeError, match="Decoding failed"):
+            ix.decode(verify=True)
+        assert np.array_equal(ix.decode(9000, 9500, verify=True).cpu().numpy(), x[:, 9000:9500])
+        out, _ = ix.decode_slices([0, 2], [0, 10], [50, 60], verify=True)  # streams 0 and 2 are intact
+        assert np.array_equal(out.cpu().numpy(), np.concatenate([x[0, :50], x[2, 10:70]]))
+        with pytest.raises(RuntimeError, match="Decoding failed"):
+            ix.decode_slices([1], [0], [50], verify=True)
+    finally:
+        ix.close()
 
 
 def test_float_array_path(fa, oracle):
