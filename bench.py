@@ -64,6 +64,21 @@ def measured_traffic(kernel):
     return None
 
 
+def measured_issue(kernel):
+    """Issue-side picture of `kernel` from the newest committed PMC pass that has one (profiles/r*_traffic.json,
+    key "issue": share of a wave's life spent issuing vector instructions x waves per SIMD); None if there is none."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            for name, rec in json.load(open(path)).get("issue", {}).items():
+                if kernel in name:
+                    return dict(rec, source=os.path.basename(path))
+        except Exception:
+            continue
+    return None
+
+
 def cpu_baseline(n_samp, seconds_budget=25.0):
     """Time the CPU oracle (a port, not libFLAC: libFLAC is absent from this image) on a bounded
     sample of the same workload with every host core."""
@@ -84,12 +99,39 @@ def cpu_baseline(n_samp, seconds_budget=25.0):
     y = O.decode_i32(blob, st, nb, n_samp, use_threads=True)
     t2 = time.perf_counter()
     assert np.array_equal(x, y)
+    # SURVEY 8(d) / BASELINE.md 2: the one-thread figure beside the all-cores one (a 16-channel slice of the same sample)
+    O.lib().oracle_set_threads(1)
+    x1 = x[:16]
+    s0 = time.perf_counter()
+    b1, st1, nb1 = O.encode_i32(x1, 5, use_threads=False)
+    s1 = time.perf_counter()
+    y1 = O.decode_i32(b1, st1, nb1, n_samp, use_threads=False)
+    s2 = time.perf_counter()
+    assert np.array_equal(x1, y1)
+    O.lib().oracle_set_threads(threads)
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+    except OSError:
+        pass
+    cflags = "unknown"
+    try:
+        with open(os.path.join(ROOT, "oracle", "Makefile")) as f:
+            cflags = next((ln.split("=", 1)[1].strip() for ln in f if ln.startswith("CFLAGS")), "unknown")
+    except OSError:
+        pass
     out = {
         "value": round(x.size / (t2 - t0) / 1e6, 2),
         "unit": "Msamples/s",
         "cores": int(threads),
         "kind": "port",
         "sample": f"{n_ch}ch x {n_samp} int32 sinusoid+noise, level 5, encode {x.size/(t1-t0)/1e6:.1f} + decode {x.size/(t2-t1)/1e6:.1f} Msamples/s",
+        "cpu_model": cpu_model,
+        "host_cores_visible": os.cpu_count(),
+        "threads_1": {"value": round(x1.size / (s2 - s0) / 1e6, 2), "unit": "Msamples/s",
+                      "sample": f"16ch x {n_samp}, one thread: encode {x1.size/(s1-s0)/1e6:.1f} + decode {x1.size/(s2-s1)/1e6:.1f} Msamples/s"},
+        "compiler": "gcc " + cflags,
     }
     # a system libFLAC, if this box has one, gives the reference's own engine (one thread, through the
     # ctypes harness of oracle/libflac_harness.py) and a cross-decode of the port's streams
@@ -172,6 +214,10 @@ def bench_cfg3(torch, fa, L, n_ch, n_samp, level, dev, steps=3):
     dt = (time.perf_counter() - t0) / steps
     L.fa_profile_enable(0)
     err = float(((y - xf).abs() / (0.5 * q[:, None])).max())  # in units of half a quantum (<= 1 + float32 rounding)
+    # the tolerance north_star states (tests/array.py:251-260: |x' - x| <= quanta / 2), plus the float32 rounding of the
+    # restore's multiply and add at the magnitude of the data: 4 eps |x| in units of half a quantum
+    bound = 1.0 + 4.0 * float(np.finfo(np.float32).eps) * float(xf.abs().max()) / float(0.5 * q.min())
+    assert err <= bound, f"configuration 3: worst error {err} half quanta exceeds {bound}"
     return {
         "workload": f"{n_ch}ch x {n_samp} float32, per-channel quanta 2^-16 (1 + c mod 4), level {level}: quantise, encode, decode + restore",
         "ms_per_step": round(dt * 1e3, 3),
@@ -179,6 +225,7 @@ def bench_cfg3(torch, fa, L, n_ch, n_samp, level, dev, steps=3):
         "range_prepass_ms": round(float(np.mean(k1)), 3),  # K1a + K1b (min / max per stream); the quantisation itself runs inside the encoder
         "compressed_bytes_per_sample": round(comp.numel() / xf.numel(), 4),
         "max_abs_err_in_half_quanta": round(err, 4),
+        "max_abs_err_bound": round(bound, 4),
     }
 
 
@@ -216,10 +263,14 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the all-gather-v of the compressed blobs out of the step")
     args = ap.parse_args()
 
-    if os.environ.get("FA_BENCH_WATCHDOG_S"):  # rehearsals: dump every thread's stack and exit instead of hanging
+    # A multi-rank run that stops making progress (a rank that fell out of a collective) must end with every thread's
+    # stack and a non-zero exit, not with the driver's kill: on by default when WORLD_SIZE > 1 (FA_BENCH_WATCHDOG_S
+    # overrides the 900 s; 0 disables).  Never a re-exec.
+    wd = os.environ.get("FA_BENCH_WATCHDOG_S", "900" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "0")
+    if int(wd) > 0:
         import faulthandler
 
-        faulthandler.dump_traceback_later(int(os.environ["FA_BENCH_WATCHDOG_S"]), exit=True)
+        faulthandler.dump_traceback_later(int(wd), exit=True)
 
     if not args.no_cpu_baseline and int(os.environ.get("WORLD_SIZE", "1")) == 1:
         # the CPU checker is compiled (if stale) before anything touches the GPU: no compiler child process
@@ -257,57 +308,85 @@ def main():
     x = make_data(torch, n_ch, n_samp, 123456789 + rank, dev)
     ws = EncodeWorkspace()
     n_global = n_ch * world
-    gather_state = {"on": world > 1 and not args.no_gather, "error": None, "bytes": 0, "local": 0, "events": []}
+    gather_state = {"on": world > 1 and not args.no_gather, "error": None, "bytes": 0, "local": 0, "ms": []}
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
+    def all_agree_ok(ok):
+        """The ranks decide TOGETHER whether the assembly leg stays in the step: a rank that failed on its own and
+        switched collectives by itself would leave the others waiting in the old one."""
+        flag = torch.tensor([0 if ok else 1], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return int(flag.item()) == 0
+
+    def step(with_gather):
         comp, st, nb = fa.encode_flac_device(x, level=args.level, workspace=ws)
+        pending = None
         if world > 1:
             # Configuration 4: the global (compressed, stream_starts, stream_nbytes) triple on every GPU --
             # all-gather of the per-stream byte counts + exclusive scan (global_bytes, mpi.py:156-187), then the
-            # all-gather-v of the shard blobs over xGMI (one batched round of point-to-point transfers).  A failure
-            # of the never-before-run RCCL leg is recorded and the remaining steps run without it.
-            if gather_state["on"]:
-                try:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    g_blob, _, _ = fdist.assemble_global(comp, nb.reshape(-1), n_global)
-                    e1.record()
-                    gather_state["events"].append((e0, e1))
-                    gather_state["bytes"] = int(g_blob.numel())
-                    gather_state["local"] = int(comp.numel())
-                    del g_blob
-                except Exception as e:  # noqa: BLE001
-                    gather_state["on"] = False
-                    gather_state["error"] = f"{type(e).__name__}: {e}"[:300]
-            if not gather_state["on"]:
+            # all-gather-v of the shard blobs over xGMI (one batched round of point-to-point transfers) on a side
+            # stream, UNDER the decode of the same step, which needs only the local blob.
+            if with_gather:
+                pending = fdist.assemble_global_async(comp, nb.reshape(-1), n_global)
+            else:
                 fdist.gather_stream_nbytes(nb.reshape(-1), n_global)
         y = fa.decode_flac_device(comp, st, nb, n_samp)
+        if pending is not None:
+            g_blob, _, _ = pending.wait()
+            gather_state["bytes"] = int(g_blob.numel())
+            gather_state["local"] = int(comp.numel())
+            ms = pending.elapsed_ms()
+            if ms is not None:
+                gather_state["ms"].append(ms)
+            del g_blob
         return comp, st, nb, y
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    L.fa_profile_enable(1)
-    prof = []
-    t0 = time.perf_counter()
-    comp = st = nb = y = None
-    for _ in range(args.steps):
-        comp = st = nb = y = None  # hand the previous outputs back to the caching allocator (no hipMalloc in the timed region)
-        comp, st, nb, y = step()
-        prof.append(profile_read(L))
-    sync()
-    t1 = time.perf_counter()
-    L.fa_profile_enable(0)
-    elapsed = t1 - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def timed_loop(with_gather):
+        for _ in range(args.warmup):
+            step(with_gather)
+        sync()
+        L.fa_profile_enable(1)
+        prof = []
+        t0 = time.perf_counter()
+        comp = st = nb = y = None
+        for _ in range(args.steps):
+            comp = st = nb = y = None  # hand the previous outputs back to the caching allocator (no hipMalloc in the timed region)
+            comp, st, nb, y = step(with_gather)
+            prof.append(profile_read(L))
+        sync()
+        t1 = time.perf_counter()
+        L.fa_profile_enable(0)
+        elapsed = t1 - t0
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return elapsed, prof, comp, st, nb, y
+
+    compute_only = None
+    if gather_state["on"]:
+        # one rehearsal step decides, for all ranks together, whether the never-before-run RCCL leg is usable
+        ok = True
+        try:
+            step(True)
+        except Exception as e:  # noqa: BLE001
+            ok = False
+            gather_state["error"] = f"{type(e).__name__}: {e}"[:300]
+        if not all_agree_ok(ok):
+            gather_state["on"] = False
+            gather_state["error"] = gather_state["error"] or "another rank failed in the all-gather-v rehearsal step"
+        gather_state["ms"].clear()
+    if world > 1 and gather_state["on"]:
+        # the same K steps without the blobs (32 KiB of byte counts per rank and step): the kernels' own scaling
+        e_c, _, comp, st, nb, y = timed_loop(False)
+        compute_only = {"ms_per_step": round(e_c / args.steps * 1e3, 3), "value": round(n_ch * n_samp * world / (e_c / args.steps) / 1e6, 1),
+                        "unit": "Msamples/s", "what": "same loop, all-gather of the stream byte counts only"}
+        comp = st = nb = y = None
+    elapsed, prof, comp, st, nb, y = timed_loop(gather_state["on"])
 
     # correctness of what was timed (outside the timed region)
     assert torch.equal(y, x), "decode(encode(x)) != x"
@@ -316,17 +395,24 @@ def main():
     cfg5 = cfg3 = None
     if not args.no_extra:
         if world > 1:
-            # configuration 5 on the sharded store: every request goes to the GPU that owns its channel
+            # configuration 5 on the sharded store: every rank keeps ITS shard resident (FlacArray + decode index) and
+            # dist.route_slices sends every request to the GPU that owns its channel; 2 warm-ups, median of 5
+            y = None
+            store = fa.FlacArray.from_device_array(x, level=args.level)
             store_req = slice_requests(n_global, n_samp, 10000)
-            own = fdist.owner_of(store_req[0], n_global, world) == rank
-            lo = fdist.shard_range(n_global, world, rank)[0]
-            sync()
-            g0 = time.perf_counter()
-            fa.decode_slices_device(comp, st, nb, n_samp, store_req[0][own] - lo, store_req[1][own], store_req[2][own])
-            sync()
-            cfg5 = {"workload": f"10000 scattered slices of the {n_global}ch store, routed to the owning GPU (dist.route_slices rule)",
-                    "ms_per_batch": round((time.perf_counter() - g0) * 1e3, 3)}
-            cfg5["slices_per_s"] = round(10000 / (cfg5["ms_per_batch"] * 1e-3), 0)
+            times = []
+            for r in range(7):
+                sync()
+                g0 = time.perf_counter()
+                fdist.route_slices(store, store_req[0], store_req[1], store_req[2], n_global)
+                sync()
+                if r >= 2:
+                    times.append(time.perf_counter() - g0)
+            med = float(np.median(times))
+            cfg5 = {"workload": f"10000 scattered slices of the {n_global}ch store: resident shard stores, dist.route_slices (owner routing), outputs to the host per GPU",
+                    "ms_per_batch": round(med * 1e3, 3), "slices_per_s": round(10000 / med, 0), "timing": "median of 5 after 2 warm-ups, barrier to barrier"}
+            store.release_device()
+            del store
         elif rank == 0:
             cfg5 = bench_cfg5(torch, fa, comp, st, nb, n_ch, n_samp, x, dev)
 
@@ -384,10 +470,12 @@ def main():
                 "traffic": measured_traffic(dom) if (n_ch, n_samp) == (4096, 1 << 20) else None,
                 "traffic_unit": "GB per launch; constant from the newest committed PMC pass (profiles/r*_traffic.json), not measured in this run",
                 "algorithmic_bytes_per_sample": round(4 + c_bytes, 4),
-                # what actually limits the kernel (profiles/*_pmc_sq_insts.csv): instruction issue, not HBM
-                # not HBM: instruction issue at the occupancy the kernels' registers / LDS allow (K3F: three waves per SIMD, each
-                # vector-active 27 % of its life and waiting 16 % of it for its byte offset; K7: two waves, 35 % each) -- DESIGN 4
-                "limiter": "instruction_issue_at_limited_occupancy",
+                # What limits the kernels is not HBM.  K3F: vector issue at three waves per SIMD (`issue`: share of a wave's
+                # life issuing vector instructions x waves per SIMD, from the newest committed PMC pass), plus the wait for the
+                # frame's byte offset.  K7: neither -- 12 % fewer vector instructions changed nothing; its per-lane read
+                # shape (64 cache lines per load instruction) and the latency of the Rice chain do (profiles/r03_k7_experiments.md)
+                "limiter": "vector_issue" if dom != "decode_frames_kernel" else "per_lane_read_shape_and_latency",
+                "issue": measured_issue(dom),
                 # the unit is the whole sequence -- HIP events around begin..finish (K3+K4+K5, host gaps
                 # included) and around K6+K7, on the launch stream
                 "encode_sequence": {"ms": round(enc_seq, 3), "achieved": gbs(enc_seq), "frac": round(gbs(enc_seq) / HBM_PEAK_GBS, 4) if enc_seq > 0 else None},
@@ -399,14 +487,19 @@ def main():
             "decode_Msamples_per_s": round(n_local * world / (dec_seq * 1e-3) / 1e6, 1) if dec_seq > 0 else None,
         }
         if world > 1:
-            ag = {"in_step": bool(gather_state["on"]), "global_blob_bytes": gather_state["bytes"], "error": gather_state["error"]}
-            ev = gather_state["events"][-args.steps:]
-            if gather_state["on"] and ev:
-                # stream time of the assembly (byte counts + blobs) on rank 0, and what that is per GPU in received bytes
-                # (xGMI: 7 links per GPU, one per peer; the transfers of a step all run at once)
-                ag["ms"] = round(float(np.mean([a.elapsed_time(b) for a, b in ev])), 3)
-                ag["received_GBs_per_gpu"] = round((gather_state["bytes"] - gather_state["local"]) / (ag["ms"] * 1e-3) / 1e9, 1) if ag["ms"] > 0 else None
+            ag = {"in_step": bool(gather_state["on"]), "overlapped_with_decode": bool(gather_state["on"] and backend == "nccl"),
+                  "global_blob_bytes": gather_state["bytes"], "error": gather_state["error"]}
+            if gather_state["on"] and gather_state["ms"]:
+                # stream time of the blob transfers on rank 0 (side stream), and what that is per GPU in received bytes
+                # (xGMI: one link per peer, all transfers of a step at once; ~76 GB/s per link and direction)
+                ag["ms"] = round(float(np.mean(gather_state["ms"][-args.steps:])), 3)
+                recv = gather_state["bytes"] - gather_state["local"]
+                ag["received_GBs_per_gpu"] = round(recv / (ag["ms"] * 1e-3) / 1e9, 1) if ag["ms"] > 0 else None
+                ag["per_link_GBs"] = round(ag["received_GBs_per_gpu"] / (world - 1), 1) if ag["received_GBs_per_gpu"] else None
+                ag["per_link_frac_of_76GBs"] = round(ag["per_link_GBs"] / 76.0, 3) if ag["per_link_GBs"] else None
             out["allgatherv"] = ag
+            if compute_only is not None:
+                out["compute_only"] = compute_only
         if cfg5 is not None:
             out["cfg5"] = cfg5
     if not args.no_extra and world == 1:

@@ -33,7 +33,8 @@ def shard_counts(n_stream, world_size):
 def _settle(t):
     """Rule for every exchange in this module: a payload is handed to the backend only after the stream
     that produced it has drained, and collectives are issued against torch's CURRENT stream -- the stream
-    the encode / decode kernels were launched on (libflacarray.py:_stream_ptr) -- never a side stream.
+    the encode / decode kernels were launched on (libflacarray.py:_stream_ptr).  (assemble_global_async is the one
+    deliberate exception: RCCL only, blobs on a side stream ordered behind the current one by an event.)
     The C entry points already end with a hipStreamSynchronize of that stream (the byte total goes to
     the host), so this costs nothing; it makes the ordering explicit instead of implied.  See DESIGN.md
     section 6 for what this rule has to do with the two-ranks-on-one-GPU rehearsal hang of round 1."""
@@ -105,6 +106,87 @@ def all_gather_blobs(local_blob, rank_bytes, group=None):
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     return out
+
+
+class _PendingAssembly:
+    """Handle of assemble_global_async: the byte counts are in, the blobs may still be travelling."""
+
+    def __init__(self, blob, g_starts, g_nbytes, side, reqs, events):
+        self._blob, self._starts, self._nbytes = blob, g_starts, g_nbytes
+        self._side, self._reqs, self._events = side, reqs, events
+
+    def wait(self):
+        """(global blob, global starts, global nbytes); the CURRENT stream is ordered behind the transfers."""
+        import torch
+
+        for r in self._reqs:
+            r.wait()
+        self._reqs = []
+        if self._side is not None:
+            torch.cuda.current_stream(self._blob.device).wait_stream(self._side)
+            self._side = None
+        return self._blob, self._starts, self._nbytes
+
+    def elapsed_ms(self):
+        """Stream time of the blob transfers (None when they ran on the host: gloo)."""
+        if not self._events:
+            return None
+        self._events[1].synchronize()
+        return float(self._events[0].elapsed_time(self._events[1]))
+
+
+def assemble_global_async(local_blob, local_nbytes, n_stream_global, group=None):
+    """assemble_global with the all-gather-v of the blobs issued on a side stream (RCCL): the caller can keep
+    launching work that needs only its OWN shard -- the decode of the same step -- on the current stream and call
+    `.wait()` where it needs the global triple.  The byte counts (32 KiB per rank) are gathered synchronously
+    first: every rank needs them to size the receive buffer.  With gloo (CPU rehearsals) the transfers are host
+    transfers and complete inside this call; the handle then just returns the result."""
+    import torch
+    import torch.distributed as dist
+
+    g_nbytes, g_starts, rank_bytes = gather_stream_nbytes(local_nbytes, n_stream_global, group)
+    world = dist.get_world_size(group)
+    if world == 1 or dist.get_backend(group) != "nccl" or not local_blob.is_cuda:
+        return _PendingAssembly(all_gather_blobs(local_blob, rank_bytes, group), g_starts, g_nbytes, None, [], None)
+    rank = dist.get_rank(group)
+    dev = local_blob.device
+    offs = np.concatenate([[0], np.cumsum(rank_bytes)]).astype(np.int64)
+    cur = torch.cuda.current_stream(dev)
+    side = _side_stream(dev)
+    out = torch.empty(int(offs[-1]), dtype=torch.uint8, device=dev)  # (allocated on the current stream: freed there, too)
+    side.wait_stream(cur)  # the payload is complete and `out` exists before the side stream touches either
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    with torch.cuda.stream(side):
+        ev[0].record()
+        out[int(offs[rank]) : int(offs[rank + 1])] = local_blob
+        ops = []
+        for step in range(1, world):
+            dst, src = (rank + step) % world, (rank - step) % world
+            gdst = dist.get_global_rank(group, dst) if group is not None else dst
+            gsrc = dist.get_global_rank(group, src) if group is not None else src
+            if rank_bytes[rank] > 0:
+                ops.append(dist.P2POp(dist.isend, local_blob, gdst, group))
+            if rank_bytes[src] > 0:
+                ops.append(dist.P2POp(dist.irecv, out[int(offs[src]) : int(offs[src + 1])], gsrc, group))
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        for r in reqs:
+            r.wait()  # (RCCL: orders the SIDE stream behind the transfers, does not block the host)
+        ev[1].record()
+    local_blob.record_stream(side)
+    out.record_stream(side)
+    return _PendingAssembly(out, g_starts, g_nbytes, side, [], ev)
+
+
+_SIDE = {}
+
+
+def _side_stream(dev):
+    import torch
+
+    key = (dev.type, dev.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
 
 
 def assemble_global(local_blob, local_nbytes, n_stream_global, group=None):

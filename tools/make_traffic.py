@@ -74,5 +74,40 @@ for k, c in I.items():
         "salu_per_wave": round(c.get("SQ_INSTS_SALU", 0.0) / waves, 1),
         "lds_per_wave": round(c.get("SQ_INSTS_LDS", 0.0) / waves, 1),
     }
+# issue side (separate PMC pass): share of a wave's life in which it issues vector instructions, times the waves that
+# share a SIMD (K3F: 3 by its 168 registers; K7: 9 workgroups of one wave per CU by its 17.4 KB of LDS = 2.25)
+WAVES_PER_SIMD = {"encode_fused_kernel": 3.0, "decode_frames_kernel": 2.25, "encode_frames_kernel": 2.0}
+pu = glob.glob(os.path.join(src, f"{tag}_pmcU/**/*counter_collection.csv"), recursive=True)
+if pu:
+    copy_own_kernels(pu[0], os.path.join(dst, f"{tag}_pmc_issue.csv"))
+    out["issue"] = {}
+    for k, c in counters(pu[0]).items():
+        wps = next((v for n, v in WAVES_PER_SIMD.items() if n in k), None)
+        wc = c.get("SQ_WAVE_CYCLES", 0.0)
+        if not wps or not wc:
+            continue
+        out["issue"][k] = {
+            "waves_per_simd": wps,
+            "valu_active_share_of_wave_life": round(c.get("SQ_ACTIVE_INST_VALU", 0.0) / wc, 4),
+            "lds_active_share_of_wave_life": round(c.get("SQ_ACTIVE_INST_LDS", 0.0) / wc, 4),
+            "wait_any_share": round(c.get("SQ_WAIT_ANY", 0.0) / wc, 4),
+            "wait_inst_any_share": round(c.get("SQ_WAIT_INST_ANY", 0.0) / wc, 4),
+            "issue_frac": round(c.get("SQ_ACTIVE_INST_VALU", 0.0) / wc * wps, 4),
+        }
+# FETCH_SIZE calibration for K7's read shape: the micro-benchmark's reads-only kernel moves a known number of bytes
+pc = glob.glob(os.path.join(src, f"{tag}_pmcC/**/*counter_collection.csv"), recursive=True)
+if pc:
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(pc[0]))
+            if "frame_stream<64, 128, 17408, false, 1>" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"]
+    if vals:
+        known = 2048 * 256 * 9392.0  # bytes the kernel reads (frames x bytes per frame, tools/ubench/frame_stream.hip)
+        kb = sum(vals) / len(vals)
+        factor = known / (kb * 1024.0)
+        out["k7_fetch_calibration"] = {"known_bytes": known, "FETCH_SIZE_KB": kb, "bytes_per_counted_byte": round(factor, 4),
+                                       "note": "same per-lane 4 x 16 B chunk reads as K7; K7's hbm_bytes below uses this factor"}
+        for k, rec in out["kernels"].items():
+            if "decode_frames" in k:
+                rec["fetch_correction"] = round(factor, 4)
+                rec["hbm_bytes"] = (rec["FETCH_SIZE_KB"] * factor + rec["WRITE_SIZE_KB"]) * 1024.0
 json.dump(out, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -17,3 +17,11 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/${tag}_pmcW -o run -- pyt
 echo "pmcW done"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $out/${tag}_pmcI -o run -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra > $out/${tag}_pmcI.log 2>&1
 echo "pmcI done"
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES --output-format csv -d $out/${tag}_pmcU -o run -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra > $out/${tag}_pmcU.log 2>&1
+echo "pmcU done"
+# K7's read shape with a KNOWN byte count (tools/ubench/frame_stream: "reads only" kernel): calibrates FETCH_SIZE for it
+if [ -x tools/ubench/frame_stream ]; then
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmcC -o run -- tools/ubench/frame_stream > $out/${tag}_pmcC.log 2>&1
+  echo "pmcC done"
+fi
+
