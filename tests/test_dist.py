@@ -35,6 +35,10 @@ def _worker(rank, world, port, n_ch, n_samp, ret):
     # every rank can decode any stream of the assembled store
     y = O.decode_i32(g_blob.numpy(), g_starts.numpy(), g_nbytes.numpy(), n_samp)
     ok = ok and np.array_equal(y, x)
+    # the handle form bench.py uses at N > 1 (host tensors: the transfers finish inside the call)
+    pend = fdist.assemble_global_async(torch.from_numpy(blob), torch.from_numpy(nb), n_ch)
+    a_blob, a_starts, a_nbytes = pend.wait()
+    ok = ok and torch.equal(a_blob, g_blob) and torch.equal(a_starts, g_starts) and torch.equal(a_nbytes, g_nbytes) and pend.elapsed_ms() is None
     ret[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()

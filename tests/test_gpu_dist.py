@@ -58,8 +58,16 @@ def _worker(rank, world, port, n_ch, n_samp, ret):
     comp, st, nb = fa.encode_flac_device(torch.from_numpy(x[lo:hi]).cuda(), level=5)
     g_blob, g_starts, g_nbytes = fdist.assemble_global(comp, nb.reshape(-1), n_ch)
     one_blob, one_st, one_nb = fa.encode_flac_device(torch.from_numpy(x).cuda(), level=5)
+    # the same assembly through the handle bench.py uses (blobs travel under the decode of the local shard; with
+    # gloo the transfers are host transfers that finish inside the call, with RCCL they run on a side stream)
+    pend = fdist.assemble_global_async(comp, nb.reshape(-1), n_ch)
+    y_local = fa.decode_flac_device(comp, st, nb, n_samp)  # needs only the local blob
+    a_blob, a_starts, a_nbytes = pend.wait()
+    ok_async = torch.equal(a_blob, g_blob) and torch.equal(a_starts, g_starts) and torch.equal(a_nbytes, g_nbytes)
+    ok_async = ok_async and np.array_equal(y_local.cpu().numpy(), x[lo:hi]) and pend.elapsed_ms() is None
     ok = (
-        g_blob.is_cuda
+        ok_async
+        and g_blob.is_cuda
         and torch.equal(g_blob, one_blob)
         and torch.equal(g_starts, one_st.reshape(-1))
         and torch.equal(g_nbytes, one_nb.reshape(-1))
@@ -121,6 +129,7 @@ def _nccl_worker(port, ret):
     comp, st, nb = fa.encode_flac_device(torch.from_numpy(x).to(dev), level=5)
     g_nb, g_st, rank_bytes = fdist.gather_stream_nbytes(nb.reshape(-1), 6)  # device tensors through RCCL
     blob, g_st2, g_nb2 = fdist.assemble_global(comp, nb.reshape(-1), 6)
+    blob3, g_st3, g_nb3 = fdist.assemble_global_async(comp, nb.reshape(-1), 6).wait()
     t = torch.tensor([1.5], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.barrier()
@@ -128,6 +137,7 @@ def _nccl_worker(port, ret):
     ok = (
         g_nb.is_cuda and torch.equal(g_nb, nb.reshape(-1)) and torch.equal(g_st, st.reshape(-1)) and rank_bytes == [comp.numel()]
         and torch.equal(blob, comp) and torch.equal(g_st2, st.reshape(-1)) and float(t.item()) == 1.5
+        and torch.equal(blob3, comp) and torch.equal(g_st3, g_st2) and torch.equal(g_nb3, g_nb2)
     )
     ret[0] = bool(ok)
     dist.destroy_process_group()
