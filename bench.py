@@ -229,6 +229,35 @@ def bench_cfg3(torch, fa, L, n_ch, n_samp, level, dev, steps=3):
     }
 
 
+def bench_end_to_end(fa, n_ch=512, n_samp=1 << 20, level=5):
+    """numpy in -> numpy out through the reference-shaped host API (encode_i32 / decode_i32 behind encode_flac /
+    decode_flac): PCIe both ways included.  2 GiB of int32, second of two repetitions.  Never `value`."""
+    rng = np.random.default_rng(7)
+    t = np.arange(n_samp)
+    f = 5.0 / n_samp
+    wave = 2.0 * np.sin(2 * np.pi * 3 * f * t) + 6.0 * np.sin(2 * np.pi * f * t)
+    base = np.rint(65536.0 * (rng.random((64, 1)) * wave + rng.normal(0, 1, (64, n_samp)))).astype(np.int32)
+    x = np.tile(base, (n_ch // 64, 1))
+    fa.encode_flac(x[:8], level)  # library tables, staging buffers
+    comp = y = None
+    for _ in range(2):
+        comp = y = None
+        t0 = time.perf_counter()
+        comp, st, nb = fa.encode_flac(x, level)
+        t1 = time.perf_counter()
+        y = fa.decode_flac(np.asarray(comp), st, nb, n_samp)
+        t2 = time.perf_counter()
+    assert np.array_equal(y, x)
+    return {
+        "workload": f"{n_ch}ch x {n_samp} int32 ({x.nbytes / 2**30:.0f} GiB) numpy -> encode_flac -> numpy -> decode_flac -> numpy, PCIe included",
+        "encode_Gsamples_per_s": round(x.size / (t1 - t0) / 1e9, 2),
+        "decode_Gsamples_per_s": round(x.size / (t2 - t1) / 1e9, 2),
+        "encode_s": round(t1 - t0, 4),
+        "decode_s": round(t2 - t1, 4),
+        "host_input_GBs": round(x.nbytes / (t1 - t0) / 1e9, 1),
+    }
+
+
 def bench_cfg5(torch, fa, comp, st, nb, n_ch, n_samp, x, dev, n_req=10000, reps=5):
     """Configuration 5 on this rank's store: 10 000 scattered (channel, range) slices in one batched launch,
     from tensors resident in HBM."""
@@ -509,6 +538,9 @@ def main():
         L.fa_release_scratch()
         cfg3 = bench_cfg3(torch, fa, L, n_ch, n_samp, args.level, dev)
         out["cfg3"] = cfg3
+        torch.cuda.empty_cache()
+        L.fa_release_scratch()
+        out["end_to_end"] = bench_end_to_end(fa, level=args.level)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(n_samp)

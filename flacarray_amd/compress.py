@@ -1,12 +1,12 @@
 """array_compress: dtype dispatch in front of the encoder (reference: src/flacarray/compress.py:12-84).
 
 Same call signature, return tuple and error behaviour as the reference; the work happens in
-`float_to_int` (K1) and `encode_flac` (K3-K5) on the GPU.
+`encode_flac` (K3F / K3-K5) on the GPU, for float data after `float_to_int` (K1; fused into the encoder for float32).
 """
 import numpy as np
 
-from .libflacarray import encode_flac
-from .utils import float_to_int, function_timer
+from .libflacarray import encode_flac, encode_flac_f32
+from .utils import _quanta_for, _streams_of, float_to_int, function_timer
 
 _INT_KINDS = (np.dtype(np.int32), np.dtype(np.int64))
 _FLOAT_KINDS = (np.dtype(np.float32), np.dtype(np.float64))
@@ -57,6 +57,13 @@ def array_compress(arr, level=5, quanta=None, precision=None, use_threads=False)
         raise RuntimeError("Cannot set both quanta and precision")
 
     stream_quanta = None if quanta is None else _per_stream_quanta(quanta, arr.shape[:-1], kind)
+    if kind == np.dtype(np.float32):
+        # one trip over PCIe: the float32 samples go up, are quantised where the encoder loads them (same integers,
+        # offsets and gains as float_to_int: utils.c:160-243 on the device), and only the compressed bytes come back;
+        # a NaN is found on the device and raises float_to_int's error
+        lead, _, _ = _streams_of(arr)
+        q = _quanta_for(arr, lead, stream_quanta, precision)
+        return encode_flac_f32(arr, q if q.size else None, level)
     ints, offsets, gains = float_to_int(arr, quanta=stream_quanta, precision=precision)
     compressed, starts, nbytes = encode_flac(ints, level, use_threads=use_threads)
     return (compressed, starts, nbytes, offsets, gains)

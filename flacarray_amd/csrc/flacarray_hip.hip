@@ -10,12 +10,20 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
+
+#include <sys/mman.h>
+#include <time.h>
+#include <unistd.h>
 
 #include "../../include/flacarray_hip.h"
 #include "decode_kernels.hpp"
@@ -59,6 +67,7 @@ struct DeviceState {
     void* c_dp = nullptr;
     uint64_t c_epoch = 0;
     bool stamps_zeroed = false;
+    hipStream_t feed_stream = nullptr;  // the host entry points' upload stream (created once: a new stream costs tens of ms)
     // optional in-library kernel timing (HIP events on the launch stream), see fa_profile_enable
     // pairs: 0 K3 encode_frames, 1 K5 compact_frames, 2 K7 decode_frames, 3 whole encode sequence (begin .. finish),
     // 4 whole decode sequence (K6 + K7 + checks), 5 K1 float32_to_int32
@@ -1214,87 +1223,291 @@ int fa_int64_to_float64_device(const int64_t* d_input, int64_t n_stream, int64_t
 }
 
 // ---------------------------------------------------------------------------------------------
-// Host-pointer drop-ins (reference C ABI).  Data makes a PCIe round trip; streams are processed
-// in chunks sized to the free HBM.
+// Host-pointer drop-ins (reference C ABI).  Data makes a PCIe round trip: the array is cut into chunks of
+// ~256 MiB, a feeder thread uploads chunk c+1 on its own stream while this thread runs the kernels of chunk c and
+// copies its result back (PCIe is full duplex), and the pages of freshly allocated host memory -- the malloc()'d blob
+// of the encoder, the caller's output array of the decoder -- are populated by helper threads ahead of the copies
+// (first-touch faults alone ran at 16 GB/s against the link's 56, tools/pcie_probe.py).  Device memory in use: two
+// input chunks + one output chunk, whatever the array's size.
 // ---------------------------------------------------------------------------------------------
-static int encode_host(const int32_t* data, int nch, int64_t n_stream, int64_t stream_size, uint32_t level, int64_t* n_bytes,
-                       int64_t* starts, unsigned char** bytes) {
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23  // Linux >= 5.14: fault pages in, writable, without touching their contents
+#endif
+
+// Populate [p, p + n) (the page-aligned inside of it) on a helper thread; join() before the memory is freed.  Contents
+// are never written, so the helper may run beside DMA into the same range.  On kernels without MADV_POPULATE_WRITE the
+// call fails and nothing happens (the copies then fault the pages in themselves, at 16 GB/s instead of the link's 56).
+// Measured on the MI355X box (profiles/r03_host_abi.md): fresh anonymous memory populates at 19 GB/s (26 with
+// transparent huge pages) whatever the number of threads -- that rate, not PCIe, bounds both host entry points -- and a
+// populate call holds the address space's lock, which the runtime's pinning of the copy buffers and thread creation
+// need too: one helper working in 128 KiB pieces lets the uploads through (4 helpers on 32 MiB pieces delayed the
+// first upload by 40 ms).
+static double host_now() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+static bool host_trace() {  // FLACARRAY_HIP_HOST_TRACE=1: per-chunk timeline of the host entry points on stderr (tools/host_trace.py)
+    static const bool on = std::getenv("FLACARRAY_HIP_HOST_TRACE") != nullptr;
+    return on;
+}
+#define FA_HTRACE(...) do { if (host_trace()) std::fprintf(stderr, __VA_ARGS__); } while (0)
+
+struct PagePopulator {
+    std::vector<std::thread> th;
+    void start(void* p, size_t n, int nthreads, bool huge) {
+        const uintptr_t pg = (uintptr_t)sysconf(_SC_PAGESIZE);
+        uintptr_t a = ((uintptr_t)p + pg - 1) & ~(pg - 1), b = ((uintptr_t)p + n) & ~(pg - 1);
+        if (b <= a || n < (64u << 20)) return;
+        if (huge) {
+            const uintptr_t hp = 2u << 20;
+            const uintptr_t ha = (a + hp - 1) & ~(hp - 1), hb = b & ~(hp - 1);
+            if (hb > ha) (void)madvise((void*)ha, hb - ha, MADV_HUGEPAGE);
+        }
+        const uintptr_t piece = 128u << 10;
+        auto next = std::make_shared<std::atomic<uintptr_t>>(a);
+        const double t0 = host_now();
+        for (int t = 0; t < nthreads; ++t)
+            th.emplace_back([next, b, piece, t0, t] {
+                for (;;) {
+                    const uintptr_t lo = next->fetch_add(piece);
+                    if (lo >= b) break;
+                    const uintptr_t hi = lo + piece < b ? lo + piece : b;
+                    if (madvise((void*)lo, hi - lo, MADV_POPULATE_WRITE) != 0) break;
+                }
+                FA_HTRACE("  populate thread %d done after %.2f ms\n", t, (host_now() - t0) * 1e3);
+            });
+    }
+    void join() {
+        for (auto& t : th) t.join();
+        th.clear();
+    }
+    ~PagePopulator() { join(); }
+};
+
+// Uploads: chunk c goes to slot c & 1 once chunk c - 2 has been consumed.  `upload(c, slot, stream)` issues the
+// copies of one chunk; the thread waits for them and publishes the chunk.
+struct Feeder {
+    std::mutex mu;
+    std::condition_variable cv;
+    int64_t uploaded = 0, consumed = 0;  // chunks
+    int err = FA_ERROR_NONE;
+    bool stop = false;
+    std::thread th;
+    hipStream_t st = nullptr;
+    int start(int dev, int64_t n_chunks, std::function<int(int64_t, int, hipStream_t)> upload, hipStream_t* cached) {
+        if (!*cached && hipStreamCreateWithFlags(cached, hipStreamNonBlocking) != hipSuccess) return FA_ERROR_DEVICE;
+        st = *cached;
+        th = std::thread([this, dev, n_chunks, upload] {
+            if (hipSetDevice(dev) != hipSuccess) { fail(FA_ERROR_DEVICE); return; }
+            for (int64_t c = 0; c < n_chunks; ++c) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return stop || consumed + 2 > c; });
+                    if (stop) return;
+                }
+                const double t0 = host_now();
+                int rc = upload(c, (int)(c & 1), st);
+                if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = FA_ERROR_DEVICE;
+                FA_HTRACE("  feeder: chunk %lld up in %.2f ms (started %.2f)\n", (long long)c, (host_now() - t0) * 1e3, t0 * 1e3);
+                if (rc) { fail(rc); return; }
+                { std::lock_guard<std::mutex> lk(mu); uploaded = c + 1; }
+                cv.notify_all();
+            }
+        });
+        return FA_ERROR_NONE;
+    }
+    void fail(int rc) {
+        { std::lock_guard<std::mutex> lk(mu); err = rc; }
+        cv.notify_all();
+    }
+    int wait_for(int64_t c) {  // chunk c is on the device (or the feeder failed)
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return err != FA_ERROR_NONE || uploaded > c; });
+        return err;
+    }
+    void done_with(int64_t c) {
+        { std::lock_guard<std::mutex> lk(mu); consumed = c + 1; }
+        cv.notify_all();
+    }
+    void finish() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+        st = nullptr;  // (the stream stays with the device state)
+    }
+    ~Feeder() { finish(); }
+};
+
+static int64_t host_chunk_streams(int64_t n_stream, size_t bytes_per_stream, int64_t max_by_grid) {
+    // ~256 MiB per chunk, at least 8 chunks for arrays that can afford them (the first upload and the last download are
+    // not overlapped with anything), never more than the grid allows
+    const size_t total = (size_t)n_stream * bytes_per_stream;
+    size_t target = 256u << 20;
+    if (total / 8 < target) target = total / 8 > (32u << 20) ? total / 8 : (32u << 20);
+    if (const char* e = std::getenv("FLACARRAY_HIP_HOST_CHUNK_BYTES")) {  // tests: many small chunks through the pipeline
+        const long long v = std::atoll(e);
+        if (v > 0) target = (size_t)v;
+    }
+    int64_t chunk = (int64_t)(target / (bytes_per_stream ? bytes_per_stream : 1));
+    if (chunk < 1) chunk = 1;
+    if (chunk > n_stream) chunk = n_stream;
+    if (chunk > max_by_grid) chunk = max_by_grid;
+    if (chunk > (1 << 20)) chunk = 1 << 20;
+    return chunk;
+}
+
+// data: int32 (nch 1), int64 (nch 2) or float32 (f32: quantised on the device -- fused into the encoder where the
+// geometry allows, utils.c:160-243; quanta may be null; offsets / gains [n_stream] are outputs)
+static int encode_host(const void* data_v, int nch, int64_t n_stream, int64_t stream_size, uint32_t level, int64_t* n_bytes,
+                       int64_t* starts, unsigned char** bytes, bool f32 = false, const float* quanta = nullptr,
+                       float* offsets = nullptr, float* gains = nullptr) {
     FA_API_LOCK;
+    const double t_enter = host_now();
     if (level > 8) return FA_ERROR_INVALID_LEVEL;        // compress.c:144-146
     if (n_stream == 0) return FA_ERROR_ZERO_NSTREAM;     // compress.c:147-149
     if (stream_size == 0) return FA_ERROR_ZERO_STREAMSIZE;  // compress.c:150-152
     *n_bytes = 0;
     *bytes = nullptr;
     for (int64_t i = 0; i < n_stream; ++i) starts[i] = 0;
+    if (n_stream < 0 || stream_size < 0) return FA_ERROR_ZERO_NSTREAM;
     if (fa_device_count() <= 0) return FA_ERROR_DEVICE;
     EncodePlan one;
     int rc = make_plan(1, stream_size, level, &one, nch);
     if (rc) return rc;
-    size_t free_b = 0, total_b = 0;
-    FA_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const size_t per_stream = (size_t)stream_size * 4 * (size_t)nch + 2 * one.total + 4096;
-    int64_t chunk = (int64_t)((free_b / 10 * 8) / per_stream);
-    if (chunk < 1) chunk = 1;
-    if (chunk > n_stream) chunk = n_stream;
-    const int64_t max_by_grid = 0x7fffffffLL / one.nf;
-    if (chunk > max_by_grid) chunk = max_by_grid;
-    if (chunk > (1 << 20)) chunk = 1 << 20;
+    int dev = 0;
+    FA_HIP_TRY(hipGetDevice(&dev));
+    const unsigned char* data = reinterpret_cast<const unsigned char*>(data_v);
+    const size_t stream_bytes = (size_t)stream_size * 4 * (size_t)nch;
+    const int64_t chunk = host_chunk_streams(n_stream, stream_bytes, 0x7fffffffLL / one.nf);
+    const int64_t n_chunks = (n_stream + chunk - 1) / chunk;
+    const bool fused_f32 = f32 && fused_geometry(chunk, stream_size, level, true) &&
+                           (n_stream % chunk == 0 || fused_geometry(n_stream % chunk, stream_size, level, true));
 
-    std::vector<unsigned char*> parts;
-    std::vector<int64_t> part_bytes;
-    int64_t running = 0;
+    // device buffers: two input slots, output, workspace, per-stream tables
+    void *d_in2 = nullptr, *d_ws = nullptr, *d_aux = nullptr, *d_out = nullptr, *d_int = nullptr;
+    const size_t in_b = (size_t)chunk * stream_bytes;
+    const size_t in_slot = align_up(in_b, 256);
+    if ((rc = get_scratch(0, 2 * in_slot + 256, &d_in2))) return rc;
+    const int64_t wsb = (nch == 2) ? fa_encode_workspace_bytes_i64(chunk, stream_size, level)
+                                   : fa_encode_single_pass_workspace_bytes(chunk, stream_size, level);  // (the slot path's size when that runs)
+    if ((rc = get_scratch(5, (size_t)wsb, &d_ws))) return rc;
+    if ((rc = get_scratch(4, (size_t)chunk * 28 + 1024, &d_aux))) return rc;
+    int64_t* d_starts = reinterpret_cast<int64_t*>(d_aux);
+    int64_t* d_nb = d_starts + chunk;
+    float* d_q = reinterpret_cast<float*>(d_nb + chunk);
+    float* d_off = d_q + chunk;
+    float* d_gain = d_off + chunk;
+    const int64_t cap_chunk = (nch == 1) ? fa_encode_capacity_bytes(chunk, stream_size, level)
+                                         : chunk * one.nf * (int64_t)kSlotBytes * 2 + chunk * stream_header_bytes(one.nf);
+    if ((rc = get_scratch(3, (size_t)cap_chunk + 256, &d_out))) return rc;
+    if (f32 && !fused_f32 && (rc = get_scratch(11, in_b + 256, &d_int))) return rc;
+
+    // the blob: worst case reserved (address space only), populated ahead of the copies, trimmed at the end
+    const int64_t cap_total = (nch == 1 ? fa_encode_capacity_bytes(n_stream, stream_size, level)
+                                        : n_stream * one.nf * (int64_t)kSlotBytes * 2 + n_stream * stream_header_bytes(one.nf)) + 64;
+    unsigned char* blob = reinterpret_cast<unsigned char*>(std::malloc((size_t)cap_total));
+    bool reserved = (blob != nullptr);
+    if (!reserved) {  // no overcommit: fall back to growing the blob chunk by chunk
+        blob = reinterpret_cast<unsigned char*>(std::malloc(1));
+        if (!blob) return FA_ERROR_ALLOC;
+    }
+    size_t blob_cap = reserved ? (size_t)cap_total : 1;
+    FA_HTRACE("encode: buffers %.2f ms\n", (host_now() - t_enter) * 1e3);
+    PagePopulator pop;
+    // (what a typical array compresses to; the rest of the reservation stays untouched address space)
+    if (reserved) pop.start(blob, std::min<size_t>((size_t)cap_total, (size_t)n_stream * stream_bytes / 8 * 5), 1, true);
+
+    FA_HTRACE("encode: populate started %.2f ms\n", (host_now() - t_enter) * 1e3);
+    Feeder feed;
     int err = FA_ERROR_NONE;
-    for (int64_t s0 = 0; s0 < n_stream && !err; s0 += chunk) {
-        const int64_t ns = (n_stream - s0 < chunk) ? (n_stream - s0) : chunk;
-        const int64_t wsb = (nch == 2) ? fa_encode_workspace_bytes_i64(ns, stream_size, level)
-                                       : fa_encode_single_pass_workspace_bytes(ns, stream_size, level);  // (the slot path's size when that runs)
-        void *d_in = nullptr, *d_ws = nullptr, *d_aux = nullptr, *d_out = nullptr;
-        const size_t in_b = (size_t)ns * (size_t)stream_size * 4 * (size_t)nch;
-        if ((err = get_scratch(0, in_b, &d_in))) break;
-        if ((err = get_scratch(5, (size_t)wsb, &d_ws))) break;
-        if ((err = get_scratch(4, (size_t)ns * 16 + 512, &d_aux))) break;
-        int64_t* d_starts = reinterpret_cast<int64_t*>(d_aux);
-        int64_t* d_nb = d_starts + ns;
-        if (hipMemcpy(d_in, data + s0 * stream_size * nch, in_b, hipMemcpyHostToDevice) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
+    if (n_chunks > 1) {
+        err = feed.start(dev, n_chunks, [=](int64_t c, int slot, hipStream_t st) {
+            const int64_t s0 = c * chunk, ns = std::min(chunk, n_stream - s0);
+            if (hipMemcpyAsync(reinterpret_cast<char*>(d_in2) + (size_t)slot * in_slot, data + (size_t)s0 * stream_bytes, (size_t)ns * stream_bytes,
+                               hipMemcpyHostToDevice, st) != hipSuccess) return (int)FA_ERROR_DEVICE;
+            return (int)FA_ERROR_NONE;
+        }, &ds_->feed_stream);
+    }
+    int64_t running = 0;
+    FA_HTRACE("encode: set-up %.2f ms (entered at %.2f)\n", (host_now() - t_enter) * 1e3, t_enter * 1e3);
+    for (int64_t c = 0; c < n_chunks && !err; ++c) {
+        const int64_t s0 = c * chunk, ns = std::min(chunk, n_stream - s0);
+        void* d_in = reinterpret_cast<char*>(d_in2) + (size_t)(c & 1) * in_slot;
+        const double tw0 = host_now();
+        if (n_chunks > 1) {
+            if ((err = feed.wait_for(c))) break;
+        } else if (hipMemcpy(d_in, data, (size_t)ns * stream_bytes, hipMemcpyHostToDevice) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
+        const double tw1 = host_now();
         int64_t total = 0;
-        if (nch == 1 && fused_geometry(ns, stream_size, level)) {
-            const int64_t cap = fa_encode_capacity_bytes(ns, stream_size, level);
-            if ((err = get_scratch(3, (size_t)cap + 256, &d_out))) break;
+        if (f32) {
+            if (quanta && hipMemcpy(d_q, quanta + s0, (size_t)ns * 4, hipMemcpyHostToDevice) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
+            const int32_t* ints = nullptr;
+            if (fused_f32) {
+                err = fa_encode_f32_device(reinterpret_cast<const float*>(d_in), ns, stream_size, level, quanta ? d_q : nullptr, d_ws, wsb,
+                                           reinterpret_cast<unsigned char*>(d_out), cap_chunk, d_starts, d_nb, d_off, d_gain, &total, nullptr, nullptr);
+            } else {
+                err = fa_float32_to_int32_device(reinterpret_cast<const float*>(d_in), ns, stream_size, quanta ? d_q : nullptr,
+                                                 reinterpret_cast<int32_t*>(d_int), d_off, d_gain, nullptr);
+                ints = reinterpret_cast<const int32_t*>(d_int);
+                if (!err) err = fa_encode_i32_device(ints, ns, stream_size, level, d_ws, wsb, reinterpret_cast<unsigned char*>(d_out), cap_chunk,
+                                                     d_starts, d_nb, &total, nullptr, nullptr);
+            }
+            if (err) break;
+            if (hipMemcpy(offsets + s0, d_off, (size_t)ns * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(gains + s0, d_gain, (size_t)ns * 4, hipMemcpyDeviceToHost) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
+        } else if (nch == 1) {
             err = fa_encode_i32_device(reinterpret_cast<const int32_t*>(d_in), ns, stream_size, level, d_ws, wsb,
-                                       reinterpret_cast<unsigned char*>(d_out), cap, d_starts, d_nb, &total, nullptr, nullptr);
+                                       reinterpret_cast<unsigned char*>(d_out), cap_chunk, d_starts, d_nb, &total, nullptr, nullptr);
             if (err) break;
         } else {
             err = encode_device_begin(reinterpret_cast<const int32_t*>(d_in), nch, ns, stream_size, level, d_ws, wsb, d_starts, d_nb, &total, nullptr, nullptr);
             if (err) break;
-            if ((err = get_scratch(3, (size_t)total + 256, &d_out))) break;
+            if (total > cap_chunk) { err = FA_ERROR_ALLOC; break; }
             err = encode_device_finish(nch, ns, stream_size, level, d_ws, d_starts, reinterpret_cast<unsigned char*>(d_out), nullptr);
             if (err) break;
         }
-        unsigned char* hp = reinterpret_cast<unsigned char*>(std::malloc((size_t)total > 0 ? (size_t)total : 1));
-        if (!hp) { err = FA_ERROR_ALLOC; break; }
-        parts.push_back(hp);
-        part_bytes.push_back(total);
-        if (hipMemcpy(hp, d_out, (size_t)total, hipMemcpyDeviceToHost) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
+        if (n_chunks > 1) {
+            // the kernels are done with the input slot (the encode calls end with a stream synchronisation)
+            feed.done_with(c);
+        }
+        if ((size_t)(running + total) > blob_cap) {  // (only without the reservation)
+            pop.join();
+            unsigned char* nb2 = reinterpret_cast<unsigned char*>(std::realloc(blob, (size_t)(running + total)));
+            if (!nb2) { err = FA_ERROR_ALLOC; break; }
+            blob = nb2;
+            blob_cap = (size_t)(running + total);
+        }
+        const double tw2 = host_now();
+        if (hipMemcpy(blob + running, d_out, (size_t)total, hipMemcpyDeviceToHost) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
         if (hipMemcpy(starts + s0, d_starts, (size_t)ns * 8, hipMemcpyDeviceToHost) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
+        FA_HTRACE("encode chunk %lld: wait %.2f ms, kernels %.2f ms, download %.2f ms (%.1f MB) at %.2f\n", (long long)c, (tw1 - tw0) * 1e3,
+                  (tw2 - tw1) * 1e3, (host_now() - tw2) * 1e3, total / 1e6, tw0 * 1e3);
         for (int64_t i = 0; i < ns; ++i) starts[s0 + i] += running;
         running += total;
     }
+    const double tf0 = host_now();
+    feed.finish();
+    pop.join();
+    FA_HTRACE("encode: joins %.2f ms\n", (host_now() - tf0) * 1e3);
     if (err) {
-        for (auto q : parts) std::free(q);
+        std::free(blob);
         for (int64_t i = 0; i < n_stream; ++i) starts[i] = 0;
         return err;
     }
-    if (parts.size() == 1) {
-        *bytes = parts[0];
-    } else {
-        unsigned char* blob = reinterpret_cast<unsigned char*>(std::malloc((size_t)running > 0 ? (size_t)running : 1));
-        if (!blob) { for (auto q : parts) std::free(q); return FA_ERROR_ALLOC; }
-        int64_t o = 0;
-        for (size_t i = 0; i < parts.size(); ++i) { std::memcpy(blob + o, parts[i], (size_t)part_bytes[i]); o += part_bytes[i]; std::free(parts[i]); }
-        *bytes = blob;
-    }
+    // trim the reservation to the bytes written (a shrinking realloc of an mmap'd block returns its tail to the system)
+    const double tr0 = host_now();
+    unsigned char* fit = reinterpret_cast<unsigned char*>(std::realloc(blob, running > 0 ? (size_t)running : 1));
+    FA_HTRACE("encode: trim %.2f ms, whole call %.2f ms\n", (host_now() - tr0) * 1e3, (host_now() - t_enter) * 1e3);
+    *bytes = fit ? fit : blob;
     *n_bytes = running;
     return FA_ERROR_NONE;
+}
+
+int fa_encode_f32_host(const float* data, int64_t n_stream, int64_t stream_size, uint32_t level, const float* quanta, int64_t* n_bytes,
+                       int64_t* starts, unsigned char** bytes, float* offsets, float* gains) {
+    if (!offsets || !gains) return FA_ERROR_CONVERT_TYPE;
+    return encode_host(data, 1, n_stream, stream_size, level, n_bytes, starts, bytes, true, quanta, offsets, gains);
 }
 
 int encode_i32(int32_t* const data, int64_t n_stream, int64_t stream_size, uint32_t level, int64_t* n_bytes,
@@ -1317,9 +1530,64 @@ int encode_i64_threaded(int64_t* const data, int64_t n_stream, int64_t stream_si
     return encode_host(reinterpret_cast<const int32_t*>(data), 2, n_stream, stream_size, level, n_bytes, starts, bytes);
 }
 
+// One chunk of streams as the decoder wants it: the byte ranges of its streams, sorted and merged where they touch (or
+// nearly touch), packed into one device buffer.  Only those ranges are uploaded -- a keep mask that selects a few
+// streams of a large store moves the bytes of those streams, not everything between the first and the last.
+struct ChunkRanges {
+    struct Piece { int64_t src, len, dst; };
+    std::vector<Piece> pieces;
+    std::vector<int64_t> rel;  // start of every stream of the chunk inside the packed buffer
+    int64_t packed = 0;
+    bool ok = true;
+    void build(const int64_t* starts, const int64_t* nbytes, int64_t s0, int64_t ns) {
+        pieces.clear();
+        rel.assign((size_t)ns, 0);
+        packed = 0;
+        ok = true;
+        std::vector<int64_t> order((size_t)ns);
+        for (int64_t i = 0; i < ns; ++i) {
+            order[(size_t)i] = i;
+            // the C signature carries no blob length: negative or overflowing entries are all that can be refused here
+            if (starts[s0 + i] < 0 || nbytes[s0 + i] < 0 || starts[s0 + i] > INT64_MAX - nbytes[s0 + i]) ok = false;
+        }
+        if (!ok) return;
+        std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return starts[s0 + a] < starts[s0 + b]; });
+        int64_t lo = -1, hi = -1;
+        auto flush = [&]() {
+            if (lo < 0) return;
+            pieces.push_back({lo, hi - lo, packed});
+            packed += (hi - lo + 255) / 256 * 256;  // every piece starts 256-byte aligned
+        };
+        std::vector<int64_t> piece_of((size_t)ns);
+        for (int64_t k = 0; k < ns; ++k) {
+            const int64_t i = order[(size_t)k], a = starts[s0 + i], b = a + nbytes[s0 + i];
+            if (lo >= 0 && a <= hi + 4096) {
+                if (b > hi) hi = b;
+            } else {
+                flush();
+                lo = a; hi = b;
+            }
+            piece_of[(size_t)i] = (int64_t)pieces.size();  // (index of the piece being built)
+        }
+        flush();
+        if (pieces.size() > 2048) {  // too scattered for one copy per piece: everything between the first and the last byte
+            const int64_t a = pieces.front().src, b = pieces.back().src + pieces.back().len;
+            pieces.assign(1, {a, b - a, 0});
+            packed = b - a;
+            for (int64_t i = 0; i < ns; ++i) rel[(size_t)i] = starts[s0 + i] - a;
+            return;
+        }
+        for (int64_t i = 0; i < ns; ++i) {
+            const Piece& pc = pieces[(size_t)piece_of[(size_t)i]];
+            rel[(size_t)i] = pc.dst + (starts[s0 + i] - pc.src);
+        }
+    }
+};
+
 static int decode_host(const unsigned char* bytes, const int64_t* starts, const int64_t* nbytes, int64_t n_stream,
                        int64_t stream_size, int64_t first_sample, int64_t last_sample, void* data_v, int nch) {
     FA_API_LOCK;
+    const double t_enter = host_now();
     const size_t esz = 4 * (size_t)nch;  // bytes per decoded sample
     unsigned char* data = reinterpret_cast<unsigned char*>(data_v);
     int64_t first_decode, n_decode;
@@ -1327,52 +1595,85 @@ static int decode_host(const unsigned char* bytes, const int64_t* starts, const 
     if (rc) return rc;
     if (n_stream <= 0) return FA_ERROR_NONE;
     if (fa_device_count() <= 0) return FA_ERROR_DEVICE;
-    size_t free_b = 0, total_b = 0;
-    FA_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const size_t per_stream = (size_t)n_decode * esz * (nch == 2 ? 2 : 1) + (size_t)stream_size * (esz + 1) + 65536;
-    int64_t chunk = (int64_t)((free_b / 10 * 7) / per_stream);
-    if (chunk < 1) chunk = 1;
-    if (chunk > n_stream) chunk = n_stream;
-    int err = FA_ERROR_NONE;
+    int dev = 0;
+    FA_HIP_TRY(hipGetDevice(&dev));
     // The reference's decoder always checks the frame CRC-16 (libFLAC reports a mismatch through the error callback,
     // decompress.c:104-121); on this entry point the check is on unless FLACARRAY_HIP_HOST_VERIFY=0 -- the bytes
     // crossed PCIe anyway, one more read of them in HBM is in the noise.
     const char* hv = std::getenv("FLACARRAY_HIP_HOST_VERIFY");
     const int host_verify = (hv && hv[0] == '0') ? 0 : 1;
-    std::vector<int64_t> st_rel;
-    for (int64_t s0 = 0; s0 < n_stream && !err; s0 += chunk) {
-        const int64_t ns = (n_stream - s0 < chunk) ? (n_stream - s0) : chunk;
-        int64_t lo = INT64_MAX, hi = 0;
-        bool bad_index = false;
-        for (int64_t i = 0; i < ns; ++i) {
-            // the C signature carries no blob length: negative or overflowing entries are all that can be refused here
-            if (starts[s0 + i] < 0 || nbytes[s0 + i] < 0 || starts[s0 + i] > INT64_MAX - nbytes[s0 + i]) { bad_index = true; break; }
-            if (starts[s0 + i] < lo) lo = starts[s0 + i];
-            if (starts[s0 + i] + nbytes[s0 + i] > hi) hi = starts[s0 + i] + nbytes[s0 + i];
-        }
-        if (bad_index || hi <= lo) { err = FA_ERROR_DECODE_INIT; break; }
-        st_rel.resize((size_t)ns);
-        for (int64_t i = 0; i < ns; ++i) st_rel[(size_t)i] = starts[s0 + i] - lo;
-        void *d_blob = nullptr, *d_aux = nullptr, *d_out = nullptr;
-        if ((err = get_scratch(0, (size_t)(hi - lo) + 256, &d_blob))) break;
-        if ((err = get_scratch(4, (size_t)ns * 16 + 512, &d_aux))) break;
-        if ((err = get_scratch(5, (size_t)ns * (size_t)n_decode * esz + 256, &d_out))) break;
-        int64_t* d_starts = reinterpret_cast<int64_t*>(d_aux);
-        int64_t* d_nb = d_starts + ns;
-        if (hipMemcpy(d_blob, bytes + lo, (size_t)(hi - lo), hipMemcpyHostToDevice) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
-        if (hipMemcpy(d_starts, st_rel.data(), (size_t)ns * 8, hipMemcpyHostToDevice) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
-        if (hipMemcpy(d_nb, nbytes + s0, (size_t)ns * 8, hipMemcpyHostToDevice) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
-        if (nch == 1)
-            err = decode_device_impl(reinterpret_cast<const unsigned char*>(d_blob), hi - lo, d_starts, d_nb, ns, stream_size,
-                                     first_decode, n_decode, -1, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<int32_t*>(d_out),
-                                     nullptr, nullptr, nullptr, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, false, host_verify);
-        else
-            err = decode_device_impl(reinterpret_cast<const unsigned char*>(d_blob), hi - lo, d_starts, d_nb, ns, stream_size,
-                                     first_decode, n_decode, -1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                     nullptr, 2, reinterpret_cast<int64_t*>(d_out), nullptr, nullptr, nullptr, nullptr, false, host_verify);
-        if (err) break;
-        if (hipMemcpy(data + (size_t)s0 * (size_t)n_decode * esz, d_out, (size_t)ns * (size_t)n_decode * esz, hipMemcpyDeviceToHost) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
+    const size_t row_bytes = (size_t)n_decode * esz;
+    const int64_t chunk = host_chunk_streams(n_stream, row_bytes, 0x7fffffffLL);
+    const int64_t n_chunks = (n_stream + chunk - 1) / chunk;
+
+    // byte ranges of every chunk (host side, cheap), and the largest packed size: the two upload slots are that large
+    std::vector<ChunkRanges> cr((size_t)n_chunks);
+    int64_t max_packed = 0;
+    for (int64_t c = 0; c < n_chunks; ++c) {
+        const int64_t s0 = c * chunk, ns = std::min(chunk, n_stream - s0);
+        cr[(size_t)c].build(starts, nbytes, s0, ns);
+        if (!cr[(size_t)c].ok || cr[(size_t)c].packed <= 0) return FA_ERROR_DECODE_INIT;
+        max_packed = std::max(max_packed, cr[(size_t)c].packed);
     }
+    void *d_blob2 = nullptr, *d_aux2 = nullptr, *d_out = nullptr;
+    const size_t blob_slot = align_up((size_t)max_packed + 256, 256);
+    const size_t aux_slot = align_up((size_t)chunk * 16 + 512, 256);
+    int err = FA_ERROR_NONE;
+    if ((err = get_scratch(0, 2 * blob_slot, &d_blob2))) return err;
+    if ((err = get_scratch(4, 2 * aux_slot, &d_aux2))) return err;
+    if ((err = get_scratch(5, (size_t)chunk * row_bytes * (nch == 2 ? 1 : 1) + 256, &d_out))) return err;
+
+    // the caller's output array is usually fresh memory (np.empty): populate its pages beside the first upload
+    FA_HTRACE("decode: buffers %.2f ms\n", (host_now() - t_enter) * 1e3);
+    PagePopulator pop;
+    pop.start(data, (size_t)n_stream * row_bytes, 1, false);
+    FA_HTRACE("decode: populate started %.2f ms\n", (host_now() - t_enter) * 1e3);
+
+    auto upload = [&, bytes, nbytes](int64_t c, int slot, hipStream_t st) -> int {
+        const int64_t s0 = c * chunk, ns = std::min(chunk, n_stream - s0);
+        const ChunkRanges& r = cr[(size_t)c];
+        char* db = reinterpret_cast<char*>(d_blob2) + (size_t)slot * blob_slot;
+        for (const auto& pc : r.pieces)
+            if (hipMemcpyAsync(db + pc.dst, bytes + pc.src, (size_t)pc.len, hipMemcpyHostToDevice, st) != hipSuccess) return FA_ERROR_DEVICE;
+        char* da = reinterpret_cast<char*>(d_aux2) + (size_t)slot * aux_slot;
+        if (hipMemcpyAsync(da, r.rel.data(), (size_t)ns * 8, hipMemcpyHostToDevice, st) != hipSuccess) return FA_ERROR_DEVICE;
+        if (hipMemcpyAsync(da + (size_t)chunk * 8, nbytes + s0, (size_t)ns * 8, hipMemcpyHostToDevice, st) != hipSuccess) return FA_ERROR_DEVICE;
+        return FA_ERROR_NONE;
+    };
+    Feeder feed;
+    if (n_chunks > 1) err = feed.start(dev, n_chunks, upload, &ds_->feed_stream);
+    FA_HTRACE("decode: set-up %.2f ms (entered at %.2f)\n", (host_now() - t_enter) * 1e3, t_enter * 1e3);
+    for (int64_t c = 0; c < n_chunks && !err; ++c) {
+        const int64_t s0 = c * chunk, ns = std::min(chunk, n_stream - s0);
+        const int slot = (int)(c & 1);
+        if (n_chunks > 1) {
+            if ((err = feed.wait_for(c))) break;
+        } else {
+            if ((err = upload(0, 0, nullptr))) break;
+            if (hipStreamSynchronize(nullptr) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
+        }
+        const unsigned char* db = reinterpret_cast<const unsigned char*>(d_blob2) + (size_t)slot * blob_slot;
+        const int64_t* d_starts = reinterpret_cast<const int64_t*>(reinterpret_cast<char*>(d_aux2) + (size_t)slot * aux_slot);
+        const int64_t* d_nb = d_starts + chunk;
+        const int64_t packed = cr[(size_t)c].packed;
+        if (nch == 1)
+            err = decode_device_impl(db, packed, d_starts, d_nb, ns, stream_size, first_decode, n_decode, -1, nullptr, nullptr, nullptr, nullptr,
+                                     reinterpret_cast<int32_t*>(d_out), nullptr, nullptr, nullptr, nullptr, 1, nullptr, nullptr, nullptr, nullptr,
+                                     nullptr, false, host_verify);
+        else
+            err = decode_device_impl(db, packed, d_starts, d_nb, ns, stream_size, first_decode, n_decode, -1, nullptr, nullptr, nullptr, nullptr,
+                                     nullptr, nullptr, nullptr, nullptr, nullptr, 2, reinterpret_cast<int64_t*>(d_out), nullptr, nullptr, nullptr,
+                                     nullptr, false, host_verify);
+        if (n_chunks > 1) feed.done_with(c);  // (the decode call ends with a stream synchronisation: the slot is free)
+        if (err) break;
+        const double td0 = host_now();
+        if (hipMemcpy(data + (size_t)s0 * row_bytes, d_out, (size_t)ns * row_bytes, hipMemcpyDeviceToHost) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
+        FA_HTRACE("decode chunk %lld: download %.2f ms at %.2f\n", (long long)c, (host_now() - td0) * 1e3, td0 * 1e3);
+    }
+    const double tj0 = host_now();
+    feed.finish();
+    pop.join();
+    FA_HTRACE("decode: joins %.2f ms, whole call %.2f ms\n", (host_now() - tj0) * 1e3, (host_now() - t_enter) * 1e3);
     return err;
 }
 

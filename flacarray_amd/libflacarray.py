@@ -100,6 +100,43 @@ def _wrap_encode(fn, flatdata, n_stream, stream_size, level, dtype=np.int32):
     return (_adopt_malloc(raw.value, n_bytes.value), flat_starts, flat_nbytes)
 
 
+def encode_flac_f32(data, quanta, level):
+    """float32 array -> (compressed, starts, nbytes, offsets, gains) in one trip over PCIe (fa_encode_f32_host): the
+    samples go up once and are quantised where the encoder loads them -- the same integers, offsets, gains and bytes as
+    `float_to_int` (utils.py:246-342) followed by `encode_flac` (libflacarray.pyx:529-594), which moves the array up,
+    the integers down, and the integers up again.  `quanta`: None (from each stream's range) or one value per stream."""
+    _lib.require_device()
+    if data.dtype != np.dtype(np.float32):
+        raise ValueError("Only float32 data is supported")
+    if level < 0 or level > 8:
+        raise RuntimeError("FLAC only supports compression levels 0-8")
+    data = np.ascontiguousarray(data)
+    stream_size = data.shape[-1]
+    lead = data.shape[:-1] if data.ndim > 1 else (1,)
+    n_stream = int(np.prod(lead))
+    q = None
+    if quanta is not None:
+        q = np.ascontiguousarray(quanta, dtype=np.float32).reshape(-1)
+        if q.size != n_stream:
+            raise ValueError("quanta must have one value per stream")
+    flat_starts = np.empty(n_stream, dtype=np.int64)
+    flat_nbytes = np.empty(n_stream, dtype=np.int64)
+    offsets = np.empty(n_stream, dtype=np.float32)
+    gains = np.empty(n_stream, dtype=np.float32)
+    n_bytes = ctypes.c_int64(0)
+    raw = ctypes.c_void_p(None)
+    errcode = _lib.lib().fa_encode_f32_host(_ptr(data), n_stream, stream_size, level, _ptr(q) if q is not None else None,
+                                            ctypes.byref(n_bytes), _ptr(flat_starts), ctypes.byref(raw), _ptr(offsets), _ptr(gains))
+    if errcode & _lib.ERROR_NAN_INPUT:
+        raise RuntimeError("Cannot convert data with NaNs to integers")
+    if errcode != 0:
+        raise RuntimeError(f"Encoding failed, return code = {errcode}")
+    flat_nbytes[:-1] = np.diff(flat_starts)
+    flat_nbytes[-1] = n_bytes.value - flat_starts[-1]
+    return (_adopt_malloc(raw.value, n_bytes.value), flat_starts.reshape(lead), flat_nbytes.reshape(lead), offsets.reshape(lead),
+            gains.reshape(lead))
+
+
 def wrap_encode_i32(flatdata, n_stream, stream_size, level):
     """libflacarray.pyx:285-343"""
     return _wrap_encode(_lib.lib().encode_i32, flatdata, n_stream, stream_size, level)

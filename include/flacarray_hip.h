@@ -132,6 +132,15 @@ int fa_encode_f32_device(const float* d_data, int64_t n_stream, int64_t stream_s
                          int64_t* d_starts, int64_t* d_nbytes, float* d_offsets, float* d_gains, int64_t* h_total_bytes,
                          int32_t* d_info, void* stream);
 
+/* Host-pointer form of the fused float32 path: what array_compress does with float32 input (compress.py:50-84:
+ * float_to_int, then encode_flac) in ONE pass over PCIe -- the float32 samples go up once, are quantised where the
+ * encoder loads them (fa_encode_f32_device; geometries the single-pass kernel does not cover are quantised on the device
+ * first), and only the compressed bytes come back.  quanta may be NULL (per-stream quanta from the data range) or
+ * hold n_stream values; offsets / gains [n_stream] are outputs; *bytes is malloc()'d as in encode_i32.
+ * FA_ERROR_NAN_INPUT for a NaN. */
+int fa_encode_f32_host(const float* data, int64_t n_stream, int64_t stream_size, uint32_t level, const float* quanta,
+                       int64_t* n_bytes, int64_t* starts, unsigned char** bytes, float* offsets, float* gains);
+
 /* The same three calls for int64 input (two-channel streams); d_info, if given, holds one
  * FrameInfo per SUBFRAME: [ (stream * frames + frame) * 2 + channel ]. */
 int64_t fa_encode_workspace_bytes_i64(int64_t n_stream, int64_t stream_size, uint32_t level);

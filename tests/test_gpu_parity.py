@@ -1073,3 +1073,44 @@ def test_random_sweep_bytes_equal_oracle(fa, oracle, seed):
     assert bad == 0 and tot > 0
     bad, tot = mod.run(100, seed + 100, verbose=False, single_pass_only=True)  # geometries of the single-pass kernel only
     assert bad == 0 and tot > 0
+
+
+def test_host_abi_pipeline_many_chunks(fa, oracle, monkeypatch):
+    """The host-pointer entry points cut the array into chunks, upload chunk c+1 on a feeder thread while chunk c is
+    encoded / decoded and copied back, and place every chunk's bytes at its final offset of one reserved blob
+    (flacarray_hip.hip: encode_host / decode_host).  With the chunk size forced down to a few streams the result must
+    be what one chunk gives: the oracle's bytes, and the input back -- also for a scattered, reordered subset of the
+    streams (only their byte ranges are uploaded) and through the fused float32 entry."""
+    monkeypatch.setenv("FLACARRAY_HIP_HOST_CHUNK_BYTES", str(3 * 20000 * 4))  # 3 streams per chunk -> 13 chunks, the last one short
+    x = sinusoid_noise_i32(37, 20000, seed=77)
+    comp, st, nb = fa.encode_flac(x, 5)
+    blob_o, st_o, nb_o = oracle.encode_i32(x, 5)
+    assert np.array_equal(comp, blob_o) and np.array_equal(st, st_o) and np.array_equal(nb, nb_o)
+    assert np.array_equal(fa.decode_flac(np.asarray(comp), st, nb, 20000), x)
+    assert np.array_equal(fa.decode_flac(np.asarray(comp), st, nb, 20000, first_sample=4000, last_sample=9001), x[:, 4000:9001])
+    pick = np.array([30, 2, 17, 3, 36, 0, 18])  # scattered and out of order: arbitrary starts / nbytes (decompress.c:194-313)
+    assert np.array_equal(fa.decode_flac(np.asarray(comp), st[pick].copy(), nb[pick].copy(), 20000), x[pick])
+    # int64 (two channels) through the same pipeline
+    x64 = (x.astype(np.int64) << 20) + 12345
+    c64, s64, n64 = fa.encode_flac(x64, 5)
+    bo, so, no = oracle.encode_i64(x64, 5)
+    assert np.array_equal(c64, bo) and np.array_equal(s64, so)
+    assert np.array_equal(fa.decode_flac(np.asarray(c64), s64, n64, 20000, is_int64=True), x64)
+    # float32 in one trip (fa_encode_f32_host) == float_to_int followed by encode_flac, for a geometry the single-pass kernel
+    # takes (8192 = two full frames) and for one it does not (20000)
+    from flacarray_amd.libflacarray import encode_flac_f32
+
+    for n in (8192, 20000):
+        xf = sinusoid_noise_f32(11, n, seed=5)
+        for q in (None, np.full(11, 2.0**-12, np.float32) * (1 + np.arange(11) % 3)):
+            monkeypatch.setenv("FLACARRAY_HIP_HOST_CHUNK_BYTES", str(4 * n * 4))
+            got = encode_flac_f32(xf, q, 5)
+            ints, off, gain = fa.float_to_int(xf, quanta=None if q is None else q)
+            c2, s2, n2 = fa.encode_flac(ints, 5)
+            assert np.array_equal(got[0], c2) and np.array_equal(got[1], s2) and np.array_equal(got[2], n2)
+            assert np.array_equal(got[3], off) and np.array_equal(got[4], gain)
+    with pytest.raises(RuntimeError, match="NaNs"):
+        bad = xf.copy()
+        bad[3, 17] = np.nan
+        fa.array_compress(bad, quanta=1e-3)
+
