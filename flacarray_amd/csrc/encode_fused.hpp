@@ -1019,6 +1019,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
     }
 #endif
 
+#ifdef FA_F_ANALYSIS_ONLY  // timing experiment: what the analysis (everything up to the published size) costs on its own
+    // (no frame is written; frame_abs gets the frame's SLOT position, so that the stream-header kernel that follows
+    // stays inside the capacity buffer -- an unset frame_abs would send it out of bounds)
+    if (lane == 0) a.frame_abs[g] = g * (int64_t)kSlotBytes + (s + 1) * a.hb;
+    return;
+#endif
     // ---- writer state ------------------------------------------------------------------------------------
     kpar[lane] = (uint8_t)kbest;
     for (int i = lane; i < kFRingWords; i += 64) ring[i] = 0;
