@@ -19,7 +19,8 @@ DEPS = [
 ]
 SRC_COMPACT = os.path.join(_HERE, "csrc", "compact_unit.hip")
 SRC_FUSED = os.path.join(_HERE, "csrc", "fused_unit.hip")
-DEPS += [SRC_COMPACT, SRC_FUSED, os.path.join(_HERE, "csrc", "encode_fused.hpp"), os.path.join(_HERE, "csrc", "verify_kernels.hpp")]
+DEPS += [SRC_COMPACT, SRC_FUSED, os.path.join(_HERE, "csrc", "encode_fused.hpp"), os.path.join(_HERE, "csrc", "verify_kernels.hpp"),
+         os.path.join(_HERE, "csrc", "decode_latency.hpp")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared"]
 # The shipped library is built from three translation units: the slot encoder and the decoder (K3, K7) with LLVM's
 # max-ILP scheduling strategy (measured: K3 -4 %, K7 -2 %), the compaction kernels (K5) and the single-pass encoder

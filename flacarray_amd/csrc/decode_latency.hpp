@@ -1,0 +1,440 @@
+// decode_latency.hpp -- K7L: one WAVEFRONT decodes one frame, for launches with few frames.
+//
+// The throughput decoder (decode_frames_kernel, K7) gives every lane a frame of its own: a launch with fewer frames
+// than lanes leaves the chip idle and takes as long as one lane needs for one frame, ~1 ms -- the reference's usage
+// pattern, one small read per call (src/flacarray/array.py:409-449 -> decompress.c:281-298: seek_absolute +
+// process_single), is exactly that launch.  Here the 64 lanes of a wave share ONE frame:
+//
+//   * the frame's bytes are fetched with coalesced loads into an LDS image (big-endian words);
+//   * headers, warm-up samples and predictor description are read by all lanes alike (uniform control flow);
+//   * the Rice codes of a partition are located in parallel: the partition's bit range is cut into 64 segments, every
+//     lane parses code LENGTHS from its segment's first bit -- usually the middle of a code -- through its own segment
+//     and the next one.  Two parses that ever stand on the same bit stay together, so lane l's parse is the true one
+//     from the point where it meets it; whether it met it before its segment ended is checked exactly: the true parse
+//     enters segment l+1 where lane l (if itself verified) left segment l, and leaves it where lane l's continued parse
+//     says -- lane l+1 is verified iff it left its own segment at that same bit.  Lane 0 starts on a code boundary and
+//     is always right; the leading run of verified lanes gives entry bit and code count of their segments, a prefix sum
+//     of the counts gives every code its sample index, and a second pass decodes the values.  Segments whose lane did
+//     not verify are simply taken up by the next round (which starts where the last verified segment ended);
+//   * the predictor runs on all lanes alike (the recurrence is serial; FIXED predictors in wrapping 32-bit integers,
+//     LPC in exact doubles as in K7), only as far as the last sample the read asks for;
+//   * the requested range is stored with coalesced stores (optionally dequantised, utils.c:350-368).
+//
+// What this kernel does not take (two channels, blocks above 4096 samples, predictor orders above 12, frames that do
+// not fit the image, anything that does not parse) raises a flag and the launch is repeated by K7, which also owns
+// all error reporting.  Results are bit-identical to K7's.
+#pragma once
+#include "decode_kernels.hpp"
+
+namespace fa {
+
+#ifndef FA_LAT_X
+#define FA_LAT_X 0  // timing experiments only (wrong results): 1 = no predictor, 2 = one parse round only, 4 = no value pass
+#endif
+constexpr int kLatMaxBlock = 4096;
+constexpr int kLatImgWords = 4416;  // 17664 bytes: a 4096-sample VERBATIM frame at 32 bits per sample is 16384 + headers
+constexpr int kLatPadWords = 8;     // zero words behind the image: speculative parses may look past the frame
+constexpr uint32_t kLatUnaryMax = 1u << 16;
+
+// tasks of a tiny launch travel as a kernel argument (no upload, no synchronisation before the launch)
+struct LatInline {
+    int64_t stream[8], frame[8], first[8], last[8], out_off[8];
+    int32_t n;
+};
+
+__device__ __forceinline__ uint32_t lat_win(const uint32_t* img, uint32_t pos) {  // bits [pos, pos + 32)
+    uint32_t wi = pos >> 5;
+    wi = wi < (uint32_t)(kLatImgWords + kLatPadWords - 2) ? wi : (uint32_t)(kLatImgWords + kLatPadWords - 2);
+    const uint64_t v = ((uint64_t)img[wi] << 32) | img[wi + 1];
+    return (uint32_t)((v << (pos & 31)) >> 32);
+}
+
+// length of the Rice code that starts at bit p (0 = no stop bit within reach: not a code)
+__device__ __forceinline__ uint32_t lat_code_len(const uint32_t* img, uint32_t p, uint32_t k, uint32_t lim) {
+    uint32_t q = 0, A;
+    for (;;) {
+        A = lat_win(img, p + q);
+        if (A != 0 || p + q >= lim || q > kLatUnaryMax) break;
+        q += 32;
+    }
+    if (A == 0) return 0;
+    return q + (uint32_t)__clz((int)A) + 1u + k;
+}
+
+constexpr int kLatResPad = 16;  // the predictor loops work in whole groups: room behind the last sample of a 4096 block
+
+template <int MO>
+__device__ __forceinline__ void lat_restore_lpc(int32_t* res, const double* coef, int order, int hi) {
+    // every lane runs the same recurrence on the same LDS words (broadcast reads); one lane stores
+    double c[MO], h[MO];
+#pragma unroll
+    for (int j = 0; j < MO; ++j) {
+        c[j] = (j < order) ? coef[j] : 0.0;
+        h[j] = (j < order) ? (double)res[order - 1 - j] : 0.0;  // h[j] = x[n - 1 - j]
+    }
+    const int lane = threadIdx.x;
+    // groups of MO samples: the history rotates through the registers by renaming, not by moves; a group's residuals
+    // are fetched together before its first sample is computed (a read inside the chain would put the LDS latency on
+    // it: 0.5 ms per frame), and the last group may run past `hi` into values nobody reads
+    for (int i = order; i < hi; i += MO) {
+        int32_t r[MO], o[MO];
+#pragma unroll
+        for (int u = 0; u < MO; ++u) r[u] = res[i + u];
+#pragma unroll
+        for (int u = 0; u < MO; ++u) {
+            double sum = 0.0;
+            // x[n-1-j] lives in h[(j - u) mod MO]: the newest sample (j = 0) enters last
+#pragma unroll
+            for (int j = MO - 1; j >= 0; --j) sum = __builtin_fma(c[j], h[(j + MO - u) % MO], sum);
+            const double xd = (double)r[u] + fa_floor(sum);
+            h[(2 * MO - 1 - u) % MO] = xd;  // overwrites x[n - MO]; it is x[n - 1] for the next sample
+            o[u] = (int32_t)xd;
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < MO; ++u) res[i + u] = o[u];
+        }
+    }
+}
+
+template <bool F32>
+__global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInline inl, int* fallback) {
+    __shared__ __attribute__((aligned(16))) uint32_t img[kLatImgWords + kLatPadWords];
+    __shared__ __attribute__((aligned(16))) int32_t res[kLatMaxBlock + kLatResPad];
+    __shared__ double coef_s[12];
+    const int lane = threadIdx.x;
+    const int64_t task = blockIdx.x;
+    if (task >= a.n_tasks) return;
+    // reason bits (diagnostics only; any non-zero value makes the host repeat the launch with K7):
+    // 1 geometry / frame does not fit, 2 header, 4 subframe kind or order, 8 residual layout, 16 no parse, 32 overrun
+    auto give_up = [&](int why) __attribute__((always_inline)) {
+        if (lane == 0) atomicOr(fallback, why);
+    };
+
+    // ---- task (wave-uniform) ----
+    int64_t s, f, sl_first, sl_last, out_off;
+    if (inl.n > 0) {
+        s = inl.stream[task]; f = inl.frame[task]; sl_first = inl.first[task]; sl_last = inl.last[task]; out_off = inl.out_off[task];
+    } else if (a.task_stream) {
+        s = a.task_stream[task]; f = a.task_frame[task];
+        sl_first = a.task_first[task]; sl_last = a.task_last[task];
+        out_off = a.task_out_off[task];
+    } else {
+        s = task / a.nfr; f = a.f0 + (task - s * a.nfr);
+        sl_first = a.first; sl_last = a.first + a.n_decode;
+        out_off = s * a.n_decode;
+    }
+    const StreamMeta m = a.meta[s];
+    const int64_t at = a.ftab[s * a.nf + f];
+    const int64_t nxt = (f + 1 < a.nf) ? a.ftab[s * a.nf + f + 1] : m.end_abs;
+    if (m.first_frame < 0 || at < 0 || nxt <= at + 6 || nxt > a.blob_bytes || a.B > kLatMaxBlock || m.channels != 1) { give_up(1); return; }
+    const int64_t base = at & ~(int64_t)15;
+    const uint32_t skip = (uint32_t)(at - base);
+    const uint32_t nbytes = skip + (uint32_t)(nxt - at);
+    if (nbytes > (uint32_t)kLatImgWords * 4u) { give_up(1); return; }
+    const uint32_t frame_end_bits = nbytes * 8u;  // (includes the CRC-16; an upper bound is all that is needed)
+
+    // ---- frame image: coalesced 16-byte loads, big-endian words ----
+    {
+        const uint8_t* const lim16 = reinterpret_cast<const uint8_t*>((reinterpret_cast<uintptr_t>(a.blob + a.blob_bytes) + 15) & ~(uintptr_t)15);
+        const uint32_t pieces = (nbytes + 15u) >> 4;
+        for (uint32_t i = lane; i < pieces; i += 64) {
+            const uint8_t* q = a.blob + base + 16 * (int64_t)i;
+            uint4 d = make_uint4(0, 0, 0, 0);
+            if (q + 16 <= lim16) d = *reinterpret_cast<const uint4*>(q);
+            uint4 o;
+            o.x = __builtin_bswap32(d.x); o.y = __builtin_bswap32(d.y); o.z = __builtin_bswap32(d.z); o.w = __builtin_bswap32(d.w);
+            *reinterpret_cast<uint4*>(&img[4 * i]) = o;
+        }
+        for (uint32_t i = 4 * pieces + lane; i < (uint32_t)(kLatImgWords + kLatPadWords); i += 64) img[i] = 0;
+    }
+    __syncthreads();
+
+    // ---- uniform bit reader ----
+    uint32_t pos = skip * 8u;
+    bool bad = false;
+    auto get = [&](int n) __attribute__((always_inline)) -> uint32_t {  // n in 1..32
+        if (pos + (uint32_t)n > frame_end_bits) { bad = true; return 0u; }
+        const uint32_t v = lat_win(img, pos) >> (32 - n);
+        pos += (uint32_t)n;
+        return v;
+    };
+    auto gets = [&](int n) __attribute__((always_inline)) -> int32_t {
+        if (n == 0) return 0;
+        const uint32_t v = get(n);
+        return (int32_t)(v << (32 - n)) >> (32 - n);
+    };
+
+    // ---- frame header (RFC 9639 9.1), CRC-8 verified ----
+    int bs = 0, fbps = 0;
+    {
+        uint8_t c8 = 0;
+        const uint32_t w = get(32);
+        c8 = crc8_byte(c8, (uint8_t)(w >> 24)); c8 = crc8_byte(c8, (uint8_t)(w >> 16));
+        c8 = crc8_byte(c8, (uint8_t)(w >> 8)); c8 = crc8_byte(c8, (uint8_t)w);
+        if ((w >> 16) != 0xFFF8) bad = true;
+        const uint32_t b2 = (w >> 8) & 0xff, b3 = w & 0xff;
+        const int bsc = (int)(b2 >> 4), src = (int)(b2 & 15), ch = (int)(b3 >> 4), ssc = (int)((b3 >> 1) & 7);
+        if (ch != 0 || (b3 & 1)) bad = true;
+        const uint32_t u0 = get(8);
+        c8 = crc8_byte(c8, (uint8_t)u0);
+        int extra = 0;
+        if (u0 & 0x80) {
+            int mbit = 0x40;
+            while ((u0 & mbit) && extra < 7) { extra++; mbit >>= 1; }
+            if (extra == 0 || extra > 6) bad = true;
+        }
+        for (int i = 0; i < extra && !bad; ++i) c8 = crc8_byte(c8, (uint8_t)get(8));
+        if (bsc == 0) bad = true;
+        else if (bsc == 1) bs = 192;
+        else if (bsc <= 5) bs = 576 << (bsc - 2);
+        else if (bsc == 6) { const uint32_t v = get(8); c8 = crc8_byte(c8, (uint8_t)v); bs = (int)v + 1; }
+        else if (bsc == 7) { const uint32_t v = get(16); c8 = crc8_byte(c8, (uint8_t)(v >> 8)); c8 = crc8_byte(c8, (uint8_t)v); bs = (int)v + 1; }
+        else bs = 256 << (bsc - 8);
+        if (src == 12) { c8 = crc8_byte(c8, (uint8_t)get(8)); }
+        else if (src == 13 || src == 14) { const uint32_t v = get(16); c8 = crc8_byte(c8, (uint8_t)(v >> 8)); c8 = crc8_byte(c8, (uint8_t)v); }
+        else if (src == 15) bad = true;
+        if (get(8) != c8) bad = true;
+        switch (ssc) {
+            case 0: fbps = m.bps; break;
+            case 1: fbps = 8; break;
+            case 2: fbps = 12; break;
+            case 4: fbps = 16; break;
+            case 5: fbps = 20; break;
+            case 6: fbps = 24; break;
+            case 7: fbps = 32; break;
+            default: bad = true; break;
+        }
+    }
+    const int64_t fstart = f * (int64_t)a.B;
+    {
+        int64_t expect = a.stream_size - fstart;
+        if (expect > a.B) expect = a.B;
+        if (bs != (int)expect || bs > kLatMaxBlock) bad = true;
+    }
+    if (bad) { give_up(2); return; }
+    int64_t l0 = sl_first - fstart, h0 = sl_last - fstart;
+    if (l0 < 0) l0 = 0;
+    if (h0 > bs) h0 = bs;
+    const int lo = (int)l0, hi = (int)(h0 > l0 ? h0 : l0);  // samples [lo, hi) of this frame are wanted
+    if (hi <= lo) return;
+
+    // ---- subframe ----
+    const uint32_t sf = get(8);
+    const int tc = (int)((sf >> 1) & 0x3f);
+    int wasted = 0;
+    if (sf & 0x80) bad = true;
+    if (sf & 1) {
+        uint32_t z = 0;
+        while (!bad && get(1) == 0) { if (++z > 32) bad = true; }
+        wasted = (int)z + 1;
+    }
+    const int bps = fbps - wasted;
+    if (bps <= 0 || bps > 32) bad = true;
+    if (bad) { give_up(4); return; }
+    int order = 0;
+    bool is_lpc = false;
+    if (tc == 0) {  // CONSTANT
+        const int32_t v = gets(bps);
+        if (bad) { give_up(4); return; }
+        for (int i = lo + lane; i < hi; i += 64) res[i] = v;
+    } else if (tc == 1) {  // VERBATIM: fixed-width fields, one lane per sample
+        if (pos + (uint32_t)bps * (uint32_t)bs > frame_end_bits) { give_up(4); return; }
+        for (int i = lo + lane; i < hi; i += 64) {
+            const uint32_t v = lat_win(img, pos + (uint32_t)i * (uint32_t)bps) >> (32 - bps);
+            res[i] = (int32_t)(v << (32 - bps)) >> (32 - bps);
+        }
+    } else if ((tc >= 8 && tc <= 12) || tc >= 32) {
+        if (tc >= 32) { order = (tc & 31) + 1; is_lpc = true; }
+        else order = tc - 8;
+        if (order > bs || order > 12) { give_up(4); return; }  // (orders 13..32 exist in foreign streams: K7 takes them)
+        for (int i = 0; i < order; ++i) {
+            const int32_t v = gets(bps);
+            if (lane == 0) res[i] = v;
+        }
+        int shift = 0;
+        if (is_lpc) {
+            const int prec = (int)get(4) + 1;
+            shift = gets(5);
+            if (prec == 16 || shift < 0) bad = true;
+            const double scale = bitsd((uint64_t)(1023 - (shift < 0 ? 0 : shift)) << 52);
+            for (int j = 0; j < order; ++j) {
+                const double v = (double)gets(prec) * scale;  // pre-scaled by 2^-shift (exact, as in K7)
+                if (lane == 0) coef_s[j] = v;
+            }
+        }
+        const int method = (int)get(2);
+        const int po = (int)get(4);
+        const int plen = method ? 5 : 4, esc = method ? 31 : 15;
+        const int ps = bs >> po;
+        if (bad || method > 1 || (po > 0 && (ps << po) != bs) || ps < order) { give_up(8); return; }
+        __syncthreads();
+
+        // ---- residual: partitions in turn, the codes of a partition in parallel ----
+        uint32_t idx0 = (uint32_t)order;           // sample index of the next residual
+        uint32_t left_in_frame = (uint32_t)(bs - order);
+        for (int p = 0; p < (1 << po) && idx0 < (uint32_t)hi; ++p) {
+            uint32_t n = (uint32_t)(p == 0 ? ps - order : ps);
+            const uint32_t k = get(plen);
+            if (bad) { give_up(8); return; }
+            if ((int)k == esc) {
+                const int wbits = (int)get(5);
+                if (bad || (uint64_t)pos + (uint64_t)wbits * n > frame_end_bits) { give_up(8); return; }
+                for (uint32_t i = lane; i < n; i += 64) {
+                    int32_t v = 0;
+                    if (wbits) {
+                        const uint32_t u = lat_win(img, pos + i * (uint32_t)wbits) >> (32 - wbits);
+                        v = (int32_t)(u << (32 - wbits)) >> (32 - wbits);
+                    }
+                    res[idx0 + i] = v;
+                }
+                pos += (uint32_t)wbits * n;
+                idx0 += n;
+                left_in_frame -= n;
+                continue;
+            }
+            // nothing behind the last wanted sample is decoded
+            uint32_t want = n;
+            if (idx0 + want > (uint32_t)hi) want = (uint32_t)hi - idx0;
+            const bool last_partition_needed = (want < n);
+            uint32_t b = pos, todo = want;
+            while (todo > 0) {
+                // segment length: this partition's share of the frame's remaining bits, spread over 64 lanes; at least
+                // a few codes long so that a parse started in the middle of a code has room to fall in step
+                const uint32_t rem_bits = frame_end_bits > b ? frame_end_bits - b : 64u;
+                uint64_t est = (uint64_t)rem_bits * todo / (left_in_frame ? left_in_frame : 1u);
+                uint32_t S = (uint32_t)(est >> 6) + 1u;
+                // A parse that starts inside a code falls in step with the true one when the two land on the same bit;
+                // their distance does a random walk whose steps are the differences of the unary parts: a few codes at
+                // k = 0, around a hundred at k = 16 (noise-like data).  Segments shorter than that mostly fail their
+                // verification and the partition takes many rounds; much longer ones leave lanes without work.  Whole-frame
+                // reads of the benchmark data (k = 16..17, profiles/r03_reads.md), segments of at least 32 + c k codes:
+                // c = 0: 125 us (FIXED 0) / 197 us (LPC 8), c = 4: 64 / 185, c = 8: 99 / 221, c = 14: 154 / 274.
+                constexpr uint32_t kSegPerK = 4;
+                const uint32_t avg_bits = rem_bits / (left_in_frame ? left_in_frame : 1u) + 1u;
+                const uint32_t smin = (32u + kSegPerK * k) * avg_bits;
+                if (S < smin) S = smin;
+                const uint32_t lim = frame_end_bits + 64u;
+                // phase A: code lengths through two segments
+                uint32_t q0 = b + (uint32_t)lane * S;
+                const uint32_t lim1 = q0 + S, lim2 = lim1 + S;
+                // (a parse that finds no further stop bit has run past the frame's last code: it ends there, with the
+                // sentinel as its exit -- whatever lies behind the last code is cut off by the code count below)
+                uint32_t cx = 0, cy = 0;
+                bool ended = false;
+                while (q0 < lim1) {
+                    const uint32_t len = lat_code_len(img, q0, k, lim);
+                    if (len == 0) { ended = true; break; }
+                    q0 += len; cx++;
+                }
+                const uint32_t x = ended ? 0xffffffffu : q0;
+                while (!ended && q0 < lim2) {
+                    const uint32_t len = lat_code_len(img, q0, k, lim);
+                    if (len == 0) { ended = true; break; }
+                    q0 += len; cy++;
+                }
+                const uint32_t y = ended ? 0xffffffffu : q0;
+                // verification chain
+                const uint32_t y_prev = (uint32_t)__shfl_up((int)y, 1, 64);
+                const uint32_t x_prev = (uint32_t)__shfl_up((int)x, 1, 64);
+                const uint32_t cy_prev = (uint32_t)__shfl_up((int)cy, 1, 64);
+                // lane l is verified iff lanes 0..l-1 are and it left its segment where the true parse does
+                const bool link = (lane == 0) || (x == y_prev);
+                const uint64_t chain = __ballot(link);
+                const int L = (chain == ~0ull) ? 64 : __builtin_ctzll(~chain);  // verified lanes: 0 .. L-1 (L >= 1)
+                if (__builtin_amdgcn_readfirstlane((int)cx) == 0) { give_up(16); return; }  // not one code where one must be: damaged (K7 reports it)
+                // segment m <= min(L, 63) has a known entry and code count (from lane m - 1's continued parse)
+                const int nseg = (L < 64) ? (L + 1) : 64;
+                const bool active = lane < nseg;
+                const uint32_t entry = (lane == 0) ? b : x_prev;
+                const uint32_t cnt = active ? ((lane == 0) ? cx : cy_prev) : 0u;
+                const uint32_t incl = wave_incl_scan_u32(cnt);
+                const uint32_t first_idx = incl - cnt;
+                // phase B: values
+                uint32_t pe = entry;
+                const uint32_t seg_end = b + ((uint32_t)lane + 1u) * S;
+                bool bad_lane = false;
+                if (!(FA_LAT_X & 4) && active && first_idx < todo) {
+                    uint32_t j = first_idx;
+                    while (pe < seg_end && j < todo) {
+                        uint32_t q = 0, A;
+                        for (;;) {
+                            A = lat_win(img, pe + q);
+                            if (A != 0 || pe + q >= lim || q > kLatUnaryMax) break;
+                            q += 32;
+                        }
+                        if (A == 0) { bad_lane = true; break; }
+                        const uint32_t z = q + (uint32_t)__clz((int)A);
+                        const uint32_t lowpos = pe + z + 1u;
+                        const uint32_t low = k ? (lat_win(img, lowpos) >> (32 - k)) : 0u;
+                        const uint32_t uu = (z << k) | low;
+                        res[idx0 + j] = (int32_t)(uu >> 1) ^ -(int32_t)(uu & 1);
+                        pe = lowpos + k;
+                        ++j;
+                    }
+                }
+                if (__any(bad_lane)) { give_up(16); return; }
+                const uint64_t took = __ballot(active && first_idx < todo);
+                const int last = 63 - __builtin_clzll(took);  // (lane 0 always takes part)
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                const uint32_t done = total < todo ? total : todo;
+                b = (uint32_t)__shfl((int)pe, last, 64);
+                idx0 += done;
+                todo -= done;
+                left_in_frame -= done;
+                if (b > frame_end_bits) { give_up(32); return; }
+                if (FA_LAT_X & 2) todo = 0;
+            }
+            pos = b;
+            if (last_partition_needed) break;
+        }
+        __syncthreads();
+        // ---- predictor ----
+        if ((FA_LAT_X & 1) != 0) {
+        } else if (is_lpc) {
+            if (order <= 4) lat_restore_lpc<4>(res, coef_s, order, hi);
+            else if (order <= 8) lat_restore_lpc<8>(res, coef_s, order, hi);
+            else lat_restore_lpc<12>(res, coef_s, order, hi);
+        } else if (order > 0) {
+            // FIXED: wrapping 32-bit arithmetic is exact here (every sample fits its 32 bits; RFC 9639 9.2.5)
+            uint32_t x1 = order >= 1 ? (uint32_t)res[order - 1] : 0u, x2 = order >= 2 ? (uint32_t)res[order - 2] : 0u;
+            uint32_t x3 = order >= 3 ? (uint32_t)res[order - 3] : 0u, x4 = order >= 4 ? (uint32_t)res[order - 4] : 0u;
+            for (int i = order; i < hi; i += 4) {  // (groups of four: the reads ahead of the chain; may run past `hi`)
+                uint32_t r[4], o[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) r[u] = (uint32_t)res[i + u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    uint32_t x0;
+                    if (order == 1) x0 = r[u] + x1;
+                    else if (order == 2) x0 = r[u] + 2u * x1 - x2;
+                    else if (order == 3) x0 = r[u] + 3u * x1 - 3u * x2 + x3;
+                    else x0 = r[u] + 4u * x1 - 6u * x2 + 4u * x3 - x4;
+                    x4 = x3; x3 = x2; x2 = x1; x1 = x0;
+                    o[u] = x0;
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) res[i + u] = (int32_t)o[u];
+                }
+            }
+        }
+    } else {
+        give_up(4);
+        return;
+    }
+    __syncthreads();
+
+    // ---- store [lo, hi) ----
+    const int64_t row0 = out_off + (fstart - sl_first);
+    if constexpr (F32) {
+        const float og = a.offsets[s];
+        const float cf = (float)(1.0 / (double)a.gains[s]);  // utils.c:361
+        for (int i = lo + lane; i < hi; i += 64)
+            a.out_f32[row0 + i] = __fadd_rn(og, __fmul_rn(cf, (float)(int32_t)((uint32_t)res[i] << wasted)));  // utils.c:364
+    } else {
+        for (int i = lo + lane; i < hi; i += 64) a.out_i32[row0 + i] = (int32_t)((uint32_t)res[i] << wasted);
+    }
+}
+
+}  // namespace fa

@@ -32,6 +32,7 @@
 #endif
 #include "encode_kernels.hpp"
 #include "encode_fused.hpp"
+#include "decode_latency.hpp"
 #include "quantize_kernels.hpp"
 #include "verify_kernels.hpp"
 
@@ -347,6 +348,16 @@ int run_verify(const DecodeArgs& a, int* d_err, int* h_err, hipStream_t st, int 
     return FA_ERROR_NONE;
 }
 
+// K7L (one wavefront per frame) is used for launches of at most this many frames; above it the throughput decoder's
+// 64 frames per wave win (K7L holds ~34 KB of LDS per frame: ~1000 frames in flight, ~60-140 us each).
+// FLACARRAY_HIP_LATENCY=0 disables it, =1 forces it for every launch of up to 65535 frames (tests).
+bool latency_allowed(int64_t n_tasks) {
+    static const char* e = std::getenv("FLACARRAY_HIP_LATENCY");
+    if (e && e[0] == '0') return false;
+    if (e && e[0] == '1') return n_tasks <= 65535;
+    return n_tasks <= 2048;
+}
+
 // A decode index: what K6 derives from a store (stream metadata, the byte offset of every frame), kept in device memory
 // of its own so that many reads of one store -- the reference's usage pattern, array.py:409-449 -- do not re-parse
 // 4096 stream headers and rebuild a million-entry frame table per call (fa_decode_index_create).
@@ -385,7 +396,7 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
         d_meta = idx->meta; d_ftab = idx->ftab; d_err = idx->err; B = idx->B; nf = idx->nf;
         if (idx->nch != nch) return FA_ERROR_DECODE_INIT;
         prof_begin(4, st);
-        FA_HIP_TRY(hipMemsetAsync(d_err, 0, 16, st));
+        FA_HIP_TRY(hipMemsetAsync(d_err, 0, 32, st));
     } else {
     // the decode kernel issues 16-byte loads relative to the blob base: realign if necessary
     if (build_only && (reinterpret_cast<uintptr_t>(d_bytes) & 15)) return FA_ERROR_DECODE_INIT;  // (an index refers to the caller's bytes)
@@ -411,7 +422,7 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
     // [0]=err [1]=variant flags [2]=streams without a seek table [3]=scan passes of the longest of them
     d_err = reinterpret_cast<int*>(reinterpret_cast<char*>(p) + meta_bytes);
     int* d_sflag = d_err + 64;  // per stream: 1 = sync scan ambiguous, walk serially
-    FA_HIP_TRY(hipMemsetAsync(d_err, 0, 16, st));
+    FA_HIP_TRY(hipMemsetAsync(d_err, 0, 32, st));  // ([4]: the latency kernel's "repeat with K7" flag)
     hipLaunchKernelGGL(parse_streams_kernel, dim3((unsigned)((n_stream + 255) / 256)), dim3(256), 0, st, d_bytes, d_starts,
                        d_nbytes, n_stream, stream_size, n_bytes, d_meta, d_err);
     StreamMeta m0;
@@ -465,6 +476,11 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
     // ---- K7 ----
     DecodeArgs a;
     std::memset(&a, 0, sizeof a);
+    LatInline inl;
+    std::memset(&inl, 0, sizeof inl);
+    std::vector<int64_t> h_tasks;
+    size_t h_tasks_bytes = 0;
+    char* d_tasks = nullptr;
     a.blob = d_bytes; a.blob_bytes = n_bytes; a.meta = d_meta; a.ftab = d_ftab; a.nf = nf; a.B = B;
     a.stream_size = stream_size;
     a.out_i32 = d_out_i32; a.out_f32 = d_out_f32; a.offsets = d_offsets; a.gains = d_gains; a.err = d_err;
@@ -485,6 +501,17 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
         }
         a.n_tasks = n_tasks;
         if (a.n_tasks == 0) return FA_ERROR_NONE;
+        if (n_tasks <= 8 && nch == 1 && latency_allowed(n_tasks)) {
+            // a handful of frames: the task table rides in the kernel arguments (no upload, no synchronisation)
+            int64_t t = 0;
+            for (int64_t i = 0; i < n_slices; ++i) {
+                const int64_t s = slice_stream[i], fst = slice_first[i], cnt = slice_count[i];
+                for (int64_t f = fst / B; f <= (fst + cnt - 1) / B; ++f, ++t) {
+                    inl.stream[t] = s; inl.frame[t] = f; inl.first[t] = fst; inl.last[t] = fst + cnt; inl.out_off[t] = out_offset[i];
+                }
+            }
+            inl.n = (int32_t)n_tasks;
+        }
         // one staging vector, one copy: [stream | frame | first | last | out offset], each n_tasks long
         const size_t stp = align_up((size_t)n_tasks * 8, 256);
         std::vector<int64_t> h(5 * stp / 8);
@@ -510,8 +537,14 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
             if (rc) return rc;
         }
         char* c = reinterpret_cast<char*>(pl);
-        FA_HIP_TRY(hipMemcpyAsync(c, h.data(), 5 * stp, hipMemcpyHostToDevice, st));
-        FA_HIP_TRY(hipStreamSynchronize(st));  // the host vector goes out of scope
+        if (inl.n == 0) {
+            FA_HIP_TRY(hipMemcpyAsync(c, h.data(), 5 * stp, hipMemcpyHostToDevice, st));
+            FA_HIP_TRY(hipStreamSynchronize(st));  // the host vector goes out of scope
+        } else {
+            h_tasks.swap(h);  // (uploaded only if K7 has to repeat the launch)
+            h_tasks_bytes = 5 * stp;
+            d_tasks = c;
+        }
         a.task_stream = reinterpret_cast<const int64_t*>(c + 0 * stp);
         a.task_frame = reinterpret_cast<const int64_t*>(c + 1 * stp);
         a.task_first = reinterpret_cast<const int64_t*>(c + 2 * stp);
@@ -521,6 +554,33 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
     if (a.B > kMaxBlock * 16) return FA_ERROR_DECODE_INIT;
     const unsigned nblk = (unsigned)((a.n_tasks + 63) / 64);
     const bool f32 = (d_out_f32 != nullptr);
+    if (nch == 1 && a.B <= kLatMaxBlock && latency_allowed(a.n_tasks)) {
+        // K7L: one wavefront per frame (decode_latency.hpp).  A launch with fewer frames than the chip has lanes is
+        // latency bound in K7 (one lane per frame: ~1 ms whatever the count); frames K7L does not take set the flag
+        // and the launch is repeated by K7 below.
+        prof_begin(2, st);
+        if (f32) hipLaunchKernelGGL((decode_latency_kernel<true>), dim3((unsigned)a.n_tasks), dim3(64), 0, st, a, inl, d_err + 4);
+        else hipLaunchKernelGGL((decode_latency_kernel<false>), dim3((unsigned)a.n_tasks), dim3(64), 0, st, a, inl, d_err + 4);
+        prof_end(2, st);
+        prof_end(4, st);
+        int h8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        FA_HIP_TRY(hipMemcpyAsync(h8, d_err, 32, hipMemcpyDeviceToHost, st));
+        FA_HIP_TRY(hipStreamSynchronize(st));
+        FA_HIP_TRY(hipGetLastError());
+        const bool verifying = (verify < 0 ? g_verify.load() : verify != 0);
+        if (inl.n > 0 && (h8[4] != 0 || verifying)) {  // K7 and the CRC-16 check read the task table from memory
+            FA_HIP_TRY(hipMemcpyAsync(d_tasks, h_tasks.data(), h_tasks_bytes, hipMemcpyHostToDevice, st));
+            FA_HIP_TRY(hipStreamSynchronize(st));
+        }
+        if (h8[4] != 0 && std::getenv("FLACARRAY_HIP_LATENCY_DEBUG"))
+            std::fprintf(stderr, "flacarray_hip: latency decoder gave up (reasons %d) on a launch of %lld frames (first slice: stream %lld, sample %lld); repeating with K7\n",
+                         h8[4], (long long)a.n_tasks, (long long)(n_slices > 0 ? slice_stream[0] : -1), (long long)(n_slices > 0 ? slice_first[0] : first_decode));
+        if (h8[4] == 0) {
+            h_err[0] = h8[0];
+            if ((rc = run_verify(a, d_err, h_err, st, verify))) return rc;
+            return h_err[0];
+        }
+    }
 #ifndef FA_DEV_MINIMAL
     if (nch == 2) {
         // two-channel arrays: task-local planar image (low words), bit 32 of every sample, task status
