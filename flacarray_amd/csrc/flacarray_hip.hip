@@ -352,7 +352,7 @@ int run_verify(const DecodeArgs& a, int* d_err, int* h_err, hipStream_t st, int 
 // 64 frames per wave win (K7L holds ~34 KB of LDS per frame: ~1000 frames in flight, ~60-140 us each).
 // FLACARRAY_HIP_LATENCY=0 disables it, =1 forces it for every launch of up to 65535 frames (tests).
 bool latency_allowed(int64_t n_tasks) {
-    static const char* e = std::getenv("FLACARRAY_HIP_LATENCY");
+    const char* e = std::getenv("FLACARRAY_HIP_LATENCY");  // (read per call: the tests switch it)
     if (e && e[0] == '0') return false;
     if (e && e[0] == '1') return n_tasks <= 65535;
     return n_tasks <= 2048;

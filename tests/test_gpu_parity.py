@@ -1114,3 +1114,46 @@ def test_host_abi_pipeline_many_chunks(fa, oracle, monkeypatch):
         bad[3, 17] = np.nan
         fa.array_compress(bad, quanta=1e-3)
 
+
+def test_latency_decoder_matches_throughput_decoder(fa, oracle, monkeypatch):
+    """K7L (one wavefront per frame, csrc/decode_latency.hpp) serves launches with few frames -- the reference's usage
+    pattern, one small read per call (array.py:409-449 -> decompress.c:281-298).  For every kind of frame the encoder
+    writes (LPC / FIXED / VERBATIM / CONSTANT, wasted bits, 1152- and 4096-sample blocks, partition orders 0..6, a short
+    last frame) a batch of random slices decoded by K7L must equal the same batch decoded by K7 and the source."""
+    import torch
+
+    rng = np.random.default_rng(99)
+    n = 30000
+    kinds = {
+        "sinus": sinusoid_noise_i32(3, n, seed=5),
+        "full": full_range_i32((3, n), seed=6),
+        "small": rng.integers(-40, 40, (3, n)).astype(np.int32),
+        "wasted": (sinusoid_noise_i32(3, n, seed=7) >> 8) << 8,
+        "const": np.full((3, n), -77, np.int32),
+        "ramp": np.broadcast_to(np.arange(n, dtype=np.int32) * 3 - 5000, (3, n)).copy(),
+        "bursts": (rng.integers(-5, 5, (3, n)) * (1 + 4000 * (rng.random((3, n)) < 0.002))).astype(np.int32),
+    }
+    for name, x in kinds.items():
+        for level in (0, 3, 5, 8):
+            blob, st, nb = oracle.encode_i32(x, level)
+            dev = (torch.from_numpy(blob).cuda(), torch.from_numpy(st).cuda(), torch.from_numpy(nb).cuda())
+            ix = fa.DeviceDecodeIndex(*dev, n)
+            try:
+                ch = rng.integers(0, 3, 40)
+                cnt = rng.integers(1, 9000, 40)
+                first = np.array([rng.integers(0, n - c + 1) for c in cnt])
+                outs = {}
+                for mode in ("0", "1"):
+                    monkeypatch.setenv("FLACARRAY_HIP_LATENCY", mode)
+                    flat, off = ix.decode_slices(ch, first, cnt)
+                    outs[mode] = flat.cpu().numpy()
+                    one, _ = ix.decode_slices(ch[:1], first[:1], cnt[:1])  # a single read: the task table rides in the kernel arguments
+                    assert np.array_equal(one.cpu().numpy(), x[ch[0], first[0] : first[0] + cnt[0]]), (name, level, mode)
+                assert np.array_equal(outs["0"], outs["1"]), (name, level)
+                want = np.concatenate([x[c, f : f + k] for c, f, k in zip(ch, first, cnt)])
+                assert np.array_equal(outs["1"], want), (name, level)
+                monkeypatch.setenv("FLACARRAY_HIP_LATENCY", "1")
+                assert np.array_equal(ix.decode(100, 9100).cpu().numpy(), x[:, 100:9100])  # grid mode through K7L
+            finally:
+                ix.close()
+
