@@ -9,7 +9,7 @@ out=gpurun_out
 export TMPDIR=/tmp
 python bench.py > $out/${tag}_bench.log 2> $out/${tag}_bench.err
 echo "bench done" && tail -c 300 $out/${tag}_bench.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -o run -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -o run -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $out/${tag}_stats.log 2>&1
 echo "stats done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmcF -o run -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra > $out/${tag}_pmcF.log 2>&1
 echo "pmcF done"
