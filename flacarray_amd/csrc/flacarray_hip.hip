@@ -908,7 +908,10 @@ static int fused_encode_run(const void* d_data, bool f32, const float* d_quanta,
     FusedPlan pl;
     make_fused_plan(n_stream, stream_size, level, &pl);
     if (!d_workspace || workspace_bytes < (int64_t)pl.total) return FA_ERROR_ALLOC;
-    if (!d_bytes || capacity_bytes < pl.capacity) return FA_ERROR_ALLOC;
+    // The buffer may be smaller than the worst case (every frame VERBATIM): a frame whose offset lies outside it is not
+    // written and the call reports FA_ERROR_ALLOC -- the caller gambles on its data's compressibility and retries with
+    // fa_encode_capacity_bytes() if it loses.  It must at least hold the stream headers.
+    if (!d_bytes || capacity_bytes < n_stream * pl.hb + 64) return FA_ERROR_ALLOC;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     char* ws = reinterpret_cast<char*>(d_workspace);
     prof_begin(3, st);
@@ -1009,8 +1012,11 @@ static int fused_encode_run(const void* d_data, bool f32, const float* d_quanta,
         // itself -- and, after a scanner time-out, of every frame behind it -- unwritten: the kernels below would
         // turn those into addresses.  They run only after the error word has come back clean (one stream
         // synchronisation, ~20 us against a 15 ms kernel).
+        int64_t h_tot = 0;
         FA_HIP_TRY(hipMemcpyAsync(&h_err, a.err, 4, hipMemcpyDeviceToHost, st));
+        FA_HIP_TRY(hipMemcpyAsync(&h_tot, d_total, 8, hipMemcpyDeviceToHost, st));  // (the scanner's total: headers and tails included)
         FA_HIP_TRY(hipStreamSynchronize(st));
+        if (h_err == 1 || (h_err == 0 && h_tot > capacity_bytes)) return FA_ERROR_ALLOC;  // the blob does not fit the caller's buffer: nothing else is launched
         if (h_err) {
             std::fprintf(stderr, "flacarray_hip: single-pass encode failed (flags %d: 1 = offset outside the buffer, 2 = a frame timed out waiting for its offset, 4 = the scanner timed out)\n", h_err);
             return FA_ERROR_ENCODE_PROCESS;

@@ -310,7 +310,7 @@ class EncodeWorkspace:
         return self.buf
 
 
-def encode_flac_device(data, level=5, workspace=None, return_info=False, compact=False):
+def encode_flac_device(data, level=5, workspace=None, return_info=False, compact=False, capacity_bytes=None):
     """Encode a C-contiguous int32 (or int64: two-channel streams) CUDA tensor [..., stream_size] held in HBM.
 
     Returns (compressed uint8 tensor, starts int64 tensor, nbytes int64 tensor), all on the
@@ -321,7 +321,9 @@ def encode_flac_device(data, level=5, workspace=None, return_info=False, compact
     single-pass kernel (a short last frame goes through a slot and is moved into place afterwards): the frames are
     written straight to their final offsets inside a buffer sized for the worst case, and `compressed` is the view
     [0, total) of that buffer (it keeps the whole buffer alive; `compact=True` returns an exact-size copy instead).
-    Everything else runs the slot sequence (K3, K4, K5) and returns an exact-size tensor.
+    `capacity_bytes` sizes that buffer instead of the worst case (1.016 x the input: every frame VERBATIM): if the blob
+    does not fit, nothing outside the buffer is written and the call raises "Encoding failed, return code = 1"
+    (ERROR_ALLOC) -- retry without it.  Everything else runs the slot sequence (K3, K4, K5) and returns an exact-size tensor.
     """
     torch = _torch()
     if data.dtype != torch.int32 and data.dtype != torch.int64:
@@ -352,6 +354,8 @@ def encode_flac_device(data, level=5, workspace=None, return_info=False, compact
     total = ctypes.c_int64(0)
     if not i64 and data.data_ptr() % 16 == 0 and L.fa_encode_single_pass_supported(n_stream, stream_size, level):
         cap = L.fa_encode_capacity_bytes(n_stream, stream_size, level)
+        if capacity_bytes is not None:
+            cap = min(cap, int(capacity_bytes))
         ws = workspace.get(L.fa_encode_single_pass_workspace_bytes(n_stream, stream_size, level), data.device)
         with torch.cuda.device(data.device):
             buf = torch.empty(cap, dtype=torch.uint8, device=data.device)

@@ -112,7 +112,8 @@ int fa_encode_i32_device_finish(int64_t n_stream, int64_t stream_size, uint32_t 
  * fa_encode_single_pass_supported) ONE kernel analyses every full frame, sizes it, finds its byte offset by a
  * look-back over the frames before it and writes it -- CRC-16 included -- to its final place in d_bytes; there is
  * no per-frame slot and no compaction pass.  The caller provides d_bytes with fa_encode_capacity_bytes() bytes
- * (worst case: every frame VERBATIM) and a workspace of fa_encode_single_pass_workspace_bytes(); the encoded
+ * (worst case: every frame VERBATIM; a smaller buffer is accepted -- if the blob does not fit, nothing outside the
+ * buffer is written and the call returns FA_ERROR_ALLOC) and a workspace of fa_encode_single_pass_workspace_bytes(); the encoded
  * triple is d_bytes[0, *h_total_bytes), d_starts, d_nbytes.  Other geometries run the begin/finish sequence into
  * the same buffers.  Same bytes as begin + finish in every case. */
 int fa_encode_single_pass_supported(int64_t n_stream, int64_t stream_size, uint32_t level);

@@ -1157,3 +1157,39 @@ def test_latency_decoder_matches_throughput_decoder(fa, oracle, monkeypatch):
             finally:
                 ix.close()
 
+
+def test_single_pass_capacity_smaller_than_worst_case(fa, oracle):
+    """The single-pass encoder writes into a caller-provided buffer.  Sized below the worst case it must either hold
+    the blob (same bytes) or refuse cleanly with ERROR_ALLOC -- no frame, tail frame or stream header may be written
+    outside it (the words behind the buffer stay untouched)."""
+    import torch
+
+    from flacarray_amd import _lib
+    from flacarray_amd.libflacarray import EncodeWorkspace
+
+    for n in (8192 * 3, 8192 * 3 + 1000):  # whole frames / a short last frame per stream (slot + move)
+        x = sinusoid_noise_i32(24, n, seed=31)
+        blob_o, st_o, nb_o = oracle.encode_i32(x, 5)
+        xd = torch.from_numpy(x).cuda()
+        comp, st, nb = fa.encode_flac_device(xd, level=5, capacity_bytes=int(blob_o.size) + 64)
+        assert np.array_equal(comp.cpu().numpy(), blob_o) and np.array_equal(st.cpu().numpy(), st_o)
+        with pytest.raises(RuntimeError, match="return code = 1$"):
+            fa.encode_flac_device(xd, level=5, capacity_bytes=int(blob_o.size) // 2)
+        with pytest.raises(RuntimeError, match="return code = 1$"):
+            fa.encode_flac_device(xd, level=5, capacity_bytes=int(blob_o.size) - 8)  # only the last (tail) frame does not fit
+        # the C entry point with a guard zone behind the buffer
+        L = _lib.lib()
+        cap = int(blob_o.size) - 3000
+        buf = torch.full((cap + 65536,), 0xA5, dtype=torch.uint8, device="cuda")
+        ws = EncodeWorkspace().get(L.fa_encode_single_pass_workspace_bytes(24, n, 5), xd.device)
+        d_st = torch.empty(24, dtype=torch.int64, device="cuda")
+        d_nb = torch.empty(24, dtype=torch.int64, device="cuda")
+        import ctypes
+
+        total = ctypes.c_int64(0)
+        rc = L.fa_encode_i32_device(ctypes.c_void_p(xd.data_ptr()), 24, n, 5, ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                                    ctypes.c_void_p(buf.data_ptr()), cap, ctypes.c_void_p(d_st.data_ptr()),
+                                    ctypes.c_void_p(d_nb.data_ptr()), ctypes.byref(total), None, None)
+        assert rc == 1
+        assert bool((buf[cap:] == 0xA5).all()), "bytes behind the caller's buffer were written"
+
