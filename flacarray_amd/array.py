@@ -256,8 +256,11 @@ class FlacArray:
                 out = torch.zeros((0, n), dtype=getattr(torch, self._typestr), device=res["device"])
             else:
                 # the kept streams as one batch of slices against the index (one launch, nothing re-parsed)
-                flat, _ = self._index().decode_slices(sel, np.full(sel.size, f0, np.int64), np.full(sel.size, n, np.int64), offsets=off, gains=gain)
+                flat, _ = self._index().decode_slices(sel, np.full(sel.size, f0, np.int64), np.full(sel.size, n, np.int64), offsets=off, gains=gain,
+                                                      to_host=not as_tensor)  # (host result: copied inside the decode call)
                 out = flat.reshape(sel.size, n)
+                if not as_tensor:
+                    return out, indices
         return (out if as_tensor else out.cpu().numpy()), indices
 
     def __getitem__(self, raw_key):
@@ -350,7 +353,10 @@ class FlacArray:
                 off = torch.from_numpy(np.ascontiguousarray(self._stream_offsets).reshape(-1))
                 gain = torch.from_numpy(np.ascontiguousarray(self._stream_gains).reshape(-1))
         if res is not None:
-            out, out_off = self._index().decode_slices(streams, first, count, offsets=res["offsets"], gains=res["gains"])
+            out, out_off = self._index().decode_slices(streams, first, count, offsets=res["offsets"], gains=res["gains"], to_host=not as_tensor)
+            if not as_tensor:
+                count = np.asarray(count, dtype=np.int64)
+                return [out[o : o + c] for o, c in zip(out_off, count)]
         else:
             out, out_off = decode_slices_device(
                 comp, st, nb, self._stream_size, streams, first, count, offsets=off, gains=gain, is_int64=self._is_int64

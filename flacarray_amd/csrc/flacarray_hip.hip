@@ -382,7 +382,8 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
                        const int64_t* out_offset, int32_t* d_out_i32, float* d_out_f32, const float* d_offsets,
                        const float* d_gains, hipStream_t st, int nch = 1, int64_t* d_out_i64 = nullptr, double* d_out_f64 = nullptr,
                        const double* d_offsets64 = nullptr, const double* d_gains64 = nullptr, DecodeIndex* idx = nullptr,
-                       bool build_only = false, int verify = -1) {
+                       bool build_only = false, int verify = -1, void* h_copy = nullptr, size_t h_copy_bytes = 0,
+                       bool* h_copied = nullptr) {
     int rc = FA_ERROR_NONE;
     int h_err[4] = {0, 0, 0, 0};
     StreamMeta* d_meta = nullptr;
@@ -564,6 +565,10 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
         prof_end(2, st);
         prof_end(4, st);
         int h8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (h_copy && h_copy_bytes) {
+            // a small read wants its samples on the host: they travel with the status words, one synchronisation for both
+            FA_HIP_TRY(hipMemcpyAsync(h_copy, f32 ? (const void*)d_out_f32 : (const void*)d_out_i32, h_copy_bytes, hipMemcpyDeviceToHost, st));
+        }
         FA_HIP_TRY(hipMemcpyAsync(h8, d_err, 32, hipMemcpyDeviceToHost, st));
         FA_HIP_TRY(hipStreamSynchronize(st));
         FA_HIP_TRY(hipGetLastError());
@@ -578,6 +583,7 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
         if (h8[4] == 0) {
             h_err[0] = h8[0];
             if ((rc = run_verify(a, d_err, h_err, st, verify))) return rc;
+            if (h_copied) *h_copied = (h_copy && h_copy_bytes);
             return h_err[0];
         }
     }
@@ -1187,6 +1193,40 @@ int fa_decode_indexed(void* index, int64_t first_sample, int64_t last_sample, in
                               out_offset, nullptr, nullptr, nullptr, nullptr, st, 2, reinterpret_cast<int64_t*>(d_out_int),
                               reinterpret_cast<double*>(d_out_float), reinterpret_cast<const double*>(d_offsets),
                               reinterpret_cast<const double*>(d_gains), ix, false, verify);
+}
+
+int fa_decode_indexed_host(void* index, int64_t n_slices, const int64_t* slice_stream, const int64_t* slice_first,
+                           const int64_t* slice_count, const int64_t* out_offset, void* d_out_int, void* d_out_float,
+                           const void* d_offsets, const void* d_gains, void* h_out, int64_t out_bytes, void* stream, int verify) {
+    FA_API_LOCK;
+    DecodeIndex* ix = reinterpret_cast<DecodeIndex*>(index);
+    if (!ix || !h_out || out_bytes < 0) return FA_ERROR_DECODE_INIT;
+    {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != ix->device) return FA_ERROR_DEVICE;
+    }
+    if ((d_out_int == nullptr) == (d_out_float == nullptr)) return FA_ERROR_CONVERT_TYPE;
+    if (d_out_float && (!d_offsets || !d_gains)) return FA_ERROR_CONVERT_TYPE;
+    if (n_slices <= 0) return FA_ERROR_NONE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    bool copied = false;
+    int rc;
+    if (ix->nch == 1)
+        rc = decode_device_impl(nullptr, 0, nullptr, nullptr, 0, 0, 0, 0, n_slices, slice_stream, slice_first, slice_count, out_offset,
+                                reinterpret_cast<int32_t*>(d_out_int), reinterpret_cast<float*>(d_out_float),
+                                reinterpret_cast<const float*>(d_offsets), reinterpret_cast<const float*>(d_gains), st, 1, nullptr, nullptr,
+                                nullptr, nullptr, ix, false, verify, h_out, (size_t)out_bytes, &copied);
+    else
+        rc = decode_device_impl(nullptr, 0, nullptr, nullptr, 0, 0, 0, 0, n_slices, slice_stream, slice_first, slice_count, out_offset,
+                                nullptr, nullptr, nullptr, nullptr, st, 2, reinterpret_cast<int64_t*>(d_out_int),
+                                reinterpret_cast<double*>(d_out_float), reinterpret_cast<const double*>(d_offsets),
+                                reinterpret_cast<const double*>(d_gains), ix, false, verify);
+    if (rc) return rc;
+    if (!copied && out_bytes > 0) {
+        FA_HIP_TRY(hipMemcpyAsync(h_out, d_out_int ? d_out_int : d_out_float, (size_t)out_bytes, hipMemcpyDeviceToHost, st));
+        FA_HIP_TRY(hipStreamSynchronize(st));
+    }
+    return FA_ERROR_NONE;
 }
 
 int fa_decode_i64_device(const unsigned char* d_bytes, int64_t n_bytes, const int64_t* d_starts,

@@ -662,8 +662,9 @@ class DeviceDecodeIndex:
             raise RuntimeError(f"Decoding failed, return code = {errcode}")
         return out
 
-    def decode_slices(self, slice_stream, slice_first, slice_count, offsets=None, gains=None, verify=None):
-        """Batched random access (see decode_slices_device): returns (flat tensor, int64 numpy array of offsets)."""
+    def decode_slices(self, slice_stream, slice_first, slice_count, offsets=None, gains=None, verify=None, to_host=False):
+        """Batched random access (see decode_slices_device): returns (flat tensor, int64 numpy array of offsets);
+        `to_host`: the flat result as a numpy array instead, copied inside the decode call (one synchronisation)."""
         torch = _torch()
         slice_stream = np.ascontiguousarray(slice_stream, dtype=np.int64)
         slice_first = np.ascontiguousarray(slice_first, dtype=np.int64)
@@ -679,6 +680,18 @@ class DeviceDecodeIndex:
         if offsets is not None:
             offsets = offsets.reshape(-1).to(device=self.device, dtype=ft).contiguous()
             gains = gains.reshape(-1).to(device=self.device, dtype=ft).contiguous()
+        if to_host:
+            host = np.empty(out.numel(), dtype=np.dtype(str(dt).replace("torch.", "")))
+            with torch.cuda.device(self.device):
+                errcode = self._L.fa_decode_indexed_host(
+                    self._h, n, ctypes.c_void_p(slice_stream.ctypes.data), ctypes.c_void_p(slice_first.ctypes.data),
+                    ctypes.c_void_p(slice_count.ctypes.data), ctypes.c_void_p(out_off.ctypes.data),
+                    None if offsets is not None else _dp(out), _dp(out) if offsets is not None else None, _dp(offsets), _dp(gains),
+                    ctypes.c_void_p(host.ctypes.data), host.nbytes, _stream_ptr(), _verify_arg(verify),
+                )
+            if errcode != 0:
+                raise RuntimeError(f"Decoding failed, return code = {errcode}")
+            return host, out_off
         with torch.cuda.device(self.device):
             errcode = self._L.fa_decode_indexed(
                 self._h, -1, -1, n, ctypes.c_void_p(slice_stream.ctypes.data), ctypes.c_void_p(slice_first.ctypes.data),

@@ -181,6 +181,13 @@ int fa_decode_indexed(void* index, int64_t first_sample, int64_t last_sample, in
                       const int64_t* slice_first, const int64_t* slice_count, const int64_t* out_offset, void* d_out_int,
                       void* d_out_float, const void* d_offsets, const void* d_gains, void* stream, int verify);
 
+/* fa_decode_indexed for scattered slices whose samples are wanted on the HOST: decodes into the caller's device
+ * buffer (d_out_int / d_out_float as above) and copies its first out_bytes bytes to h_out inside the same call -- for a
+ * small read the samples travel with the status words and the call synchronises once. */
+int fa_decode_indexed_host(void* index, int64_t n_slices, const int64_t* slice_stream, const int64_t* slice_first,
+                           const int64_t* slice_count, const int64_t* out_offset, void* d_out_int, void* d_out_float,
+                           const void* d_offsets, const void* d_gains, void* h_out, int64_t out_bytes, void* stream, int verify);
+
 /* Integrity check of the decoder.  Every device decode entry point takes `verify`: 1 = re-compute the CRC-16 of each
  * frame the call read and report a mismatch as FA_ERROR_DECODE_PROCESS -- what libFLAC reports through the error
  * callback the reference prints (decompress.c:104-121) --, 0 = do not, negative = the process-wide default set here
