@@ -121,6 +121,13 @@ def cpu_baseline(n_samp, seconds_budget=25.0):
             cflags = next((ln.split("=", 1)[1].strip() for ln in f if ln.startswith("CFLAGS")), "unknown")
     except OSError:
         pass
+    # SURVEY 8(d), cfg 5 on the CPU: single-stream decode(first, last) calls at the C level, one thread
+    rch, rfirst, rcnt = slice_requests(16, n_samp, 200, seed=24680)
+    r0 = time.perf_counter()
+    for i in range(200):
+        c = int(rch[i])
+        O.decode_i32(b1, st1[c : c + 1].copy(), nb1[c : c + 1].copy(), n_samp, int(rfirst[i]), int(rfirst[i] + rcnt[i]))
+    single_read_us = (time.perf_counter() - r0) / 200 * 1e6
     out = {
         "value": round(x.size / (t2 - t0) / 1e6, 2),
         "unit": "Msamples/s",
@@ -132,6 +139,7 @@ def cpu_baseline(n_samp, seconds_budget=25.0):
         "threads_1": {"value": round(x1.size / (s2 - s0) / 1e6, 2), "unit": "Msamples/s",
                       "sample": f"16ch x {n_samp}, one thread: encode {x1.size/(s1-s0)/1e6:.1f} + decode {x1.size/(s2-s1)/1e6:.1f} Msamples/s"},
         "compiler": "gcc " + cflags,
+        "single_read_us": round(single_read_us, 1),  # one scattered (channel, range<=8192) slice per call, one thread (cfg 5 on the CPU)
     }
     # a system libFLAC, if this box has one, gives the reference's own engine (one thread, through the
     # ctypes harness of oracle/libflac_harness.py) and a cross-decode of the port's streams
@@ -277,6 +285,30 @@ def bench_cfg5(torch, fa, comp, st, nb, n_ch, n_samp, x, dev, n_req=10000, reps=
         "slices_per_s": round(n_req / dt, 0),
         "decoded_Msamples_per_s": round(float(cnt.sum()) / dt / 1e6, 1),
     }
+
+
+def bench_small_reads(fa, comp, st, nb, n_ch, n_samp, x):
+    """The reference's usage pattern (array.py:409-449: one decode call per key): single scattered reads and batches
+    of 100 from the HBM-resident store through a decode index, samples returned to the host."""
+    ch, first, cnt = slice_requests(n_ch, n_samp, 400, seed=24680)
+    ix = fa.DeviceDecodeIndex(comp, st.reshape(-1), nb.reshape(-1), n_samp)
+    try:
+        for i in range(5):
+            out, _ = ix.decode_slices(ch[i : i + 1], first[i : i + 1], cnt[i : i + 1], to_host=True)
+            assert np.array_equal(out, x[ch[i], first[i] : first[i] + cnt[i]].cpu().numpy())
+        t0 = time.perf_counter()
+        for i in range(200):
+            ix.decode_slices(ch[i : i + 1], first[i : i + 1], cnt[i : i + 1], to_host=True)
+        single = (time.perf_counter() - t0) / 200
+        ix.decode_slices(ch[:100], first[:100], cnt[:100], to_host=True)
+        t0 = time.perf_counter()
+        for r in range(20):
+            ix.decode_slices(ch[100 * (r % 4) : 100 * (r % 4) + 100], first[100 * (r % 4) : 100 * (r % 4) + 100], cnt[100 * (r % 4) : 100 * (r % 4) + 100], to_host=True)
+        b100 = (time.perf_counter() - t0) / 20
+    finally:
+        ix.close()
+    return {"workload": "scattered (channel, first, length<=8192) reads from the resident store, samples to the host",
+            "single_read_us": round(single * 1e6, 1), "batch_of_100_us": round(b100 * 1e6, 1), "batch_of_100_slices_per_s": round(100 / b100, 0)}
 
 
 def main():
@@ -444,6 +476,7 @@ def main():
             del store
         elif rank == 0:
             cfg5 = bench_cfg5(torch, fa, comp, st, nb, n_ch, n_samp, x, dev)
+            cfg5["small_reads"] = bench_small_reads(fa, comp, st, nb, n_ch, n_samp, x)
 
     if rank == 0:
         samples_per_step = n_ch * n_samp * world
