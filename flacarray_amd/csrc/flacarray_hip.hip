@@ -1373,7 +1373,7 @@ struct PagePopulator {
         const uintptr_t piece = 128u << 10;
         auto next = std::make_shared<std::atomic<uintptr_t>>(a);
         const double t0 = host_now();
-        for (int t = 0; t < nthreads; ++t)
+        for (int t = 0; t < nthreads; ++t) try {
             th.emplace_back([next, b, piece, t0, t] {
                 for (;;) {
                     const uintptr_t lo = next->fetch_add(piece);
@@ -1383,6 +1383,9 @@ struct PagePopulator {
                 }
                 FA_HTRACE("  populate thread %d done after %.2f ms\n", t, (host_now() - t0) * 1e3);
             });
+        } catch (...) {  // no thread to be had: the copies fault the pages in themselves
+            break;
+        }
     }
     void join() {
         for (auto& t : th) t.join();
@@ -1404,6 +1407,7 @@ struct Feeder {
     int start(int dev, int64_t n_chunks, std::function<int(int64_t, int, hipStream_t)> upload, hipStream_t* cached) {
         if (!*cached && hipStreamCreateWithFlags(cached, hipStreamNonBlocking) != hipSuccess) return FA_ERROR_DEVICE;
         st = *cached;
+        try {
         th = std::thread([this, dev, n_chunks, upload] {
             if (hipSetDevice(dev) != hipSuccess) { fail(FA_ERROR_DEVICE); return; }
             for (int64_t c = 0; c < n_chunks; ++c) {
@@ -1421,6 +1425,9 @@ struct Feeder {
                 cv.notify_all();
             }
         });
+        } catch (...) {
+            return FA_ERROR_ALLOC;  // (std::system_error: no thread)
+        }
         return FA_ERROR_NONE;
     }
     void fail(int rc) {

@@ -1090,6 +1090,13 @@ def test_host_abi_pipeline_many_chunks(fa, oracle, monkeypatch):
     assert np.array_equal(fa.decode_flac(np.asarray(comp), st, nb, 20000, first_sample=4000, last_sample=9001), x[:, 4000:9001])
     pick = np.array([30, 2, 17, 3, 36, 0, 18])  # scattered and out of order: arbitrary starts / nbytes (decompress.c:194-313)
     assert np.array_equal(fa.decode_flac(np.asarray(comp), st[pick].copy(), nb[pick].copy(), 20000), x[pick])
+    # more scattered byte ranges than one copy each is worth (> 2048 pieces): everything between the first and the last
+    xs = sinusoid_noise_i32(5000, 64, seed=78)
+    cs, ss, ns = fa.encode_flac(xs, 5)
+    odd = np.arange(1, 5000, 2)
+    monkeypatch.setenv("FLACARRAY_HIP_HOST_CHUNK_BYTES", str(1 << 30))  # one chunk: 2500 separate ranges in it
+    assert np.array_equal(fa.decode_flac(np.asarray(cs), ss[odd].copy(), ns[odd].copy(), 64), xs[odd])
+    monkeypatch.setenv("FLACARRAY_HIP_HOST_CHUNK_BYTES", str(3 * 20000 * 4))
     # int64 (two channels) through the same pipeline
     x64 = (x.astype(np.int64) << 20) + 12345
     c64, s64, n64 = fa.encode_flac(x64, 5)
