@@ -54,7 +54,8 @@ struct EncodeArgs {
     uint32_t* frame_bytes;  // [n_stream*nframes]
     FrameInfo* info;        // [n_stream*nframes] or null
     unsigned long long* stamps;  // diagnostic build (-DFA_STAMPS): per-phase cycle sums
-    const uint4* hdr;       // [nframes] frame header fields by frame number (see frame_header_entry)
+    const uint4* hdr;       // [nframes] frame header fields by frame number (see frame_header_entry); two-channel arrays:
+                            // [2 nframes], the second half with channel assignment side + right
     int32_t pmax_full, pmax_tail;  // max_porder_for(B / tail_bs, max_porder, 0): the part that does not depend on the predictor order
     double escale_full, escale_tail;  // 0.5 / blocksize (best_lpc_order's error scale), divided once on the host
     int32_t tail_only;  // 1: the grid is one workgroup per STREAM and encodes only its last frame, into slot [stream] (the
@@ -68,10 +69,11 @@ struct EncodeArgs {
 //   y: first (up to 4) bytes of the UTF-8 coded frame number
 //   z: remaining UTF-8 bytes (low 16 bits) | explicit blocksize bytes (high 16 bits)
 //   w: CRC-8 | bits of y << 8 | bits of the low half of z << 16 | bits of the high half of z << 24
-FA_HD uint4 frame_header_entry(uint64_t fn, int bs, int nch) {
+FA_HD uint4 frame_header_entry(uint64_t fn, int bs, int nch, bool side_right = false) {
     const int bsc = blocksize_code(bs);
     const uint32_t b2 = (uint32_t)((bsc << 4) | 9);
-    const uint32_t b3 = ((uint32_t)(nch - 1) << 4) | 0x0Eu;  // mono or two independent channels, 32 bits per sample, reserved 0
+    // mono, two independent channels, or side + right (0b1001); 32 bits per sample, reserved 0
+    const uint32_t b3 = ((side_right ? 9u : (uint32_t)(nch - 1)) << 4) | 0x0Eu;
     const int nbu = (fn < 0x80) ? 1 : (fn < 0x800) ? 2 : (fn < 0x10000) ? 3 : (fn < 0x200000) ? 4 : (fn < 0x4000000) ? 5 : 6;
     uint64_t ub = fn;  // UTF-8 coded frame number, big-endian in the low nbu bytes
     if (nbu > 1) {
@@ -492,8 +494,10 @@ __device__ __forceinline__ uint64_t rice_search_wave(uint64_t S, int bs, int pre
 // (Re)load the frame's samples from global memory into the LDS chunk image, applying the
 // wasted-bits shift.  Returns this lane's OR of valid samples and whether all equal `first`.
 // stride / choff select one channel of a sample-interleaved two-channel frame.
+// side: the channel is (word 0 - word 1) of every interleaved pair (stride 2; the caller has checked that it fits 32 bits).
 __device__ __forceinline__ void load_frame(const int32_t* __restrict__ src, int bs, int wasted, int32_t* smp, int lane,
-                                           uint32_t* orv_out, bool* alleq_out, int32_t first, int stride = 1, int choff = 0) {
+                                           uint32_t* orv_out, bool* alleq_out, int32_t first, int stride = 1, int choff = 0,
+                                           bool side = false) {
     const bool aligned = (stride == 1) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
     const int nrows = (bs + kRow - 1) / kRow;
     uint32_t orv = 0;
@@ -508,6 +512,12 @@ __device__ __forceinline__ void load_frame(const int32_t* __restrict__ src, int 
             if (base + 1 < bs) v.y = src[(size_t)(base + 1) * stride + choff];
             if (base + 2 < bs) v.z = src[(size_t)(base + 2) * stride + choff];
             if (base + 3 < bs) v.w = src[(size_t)(base + 3) * stride + choff];
+            if (side) {
+                if (base + 0 < bs) v.x -= src[(size_t)(base + 0) * stride + 1];
+                if (base + 1 < bs) v.y -= src[(size_t)(base + 1) * stride + 1];
+                if (base + 2 < bs) v.z -= src[(size_t)(base + 2) * stride + 1];
+                if (base + 3 < bs) v.w -= src[(size_t)(base + 3) * stride + 1];
+            }
         }
         if (base + 0 < bs) { orv |= (uint32_t)v.x; alleq = alleq && (v.x == first); }
         if (base + 1 < bs) { orv |= (uint32_t)v.y; alleq = alleq && (v.y == first); }
@@ -527,6 +537,8 @@ __device__ __forceinline__ void load_frame(const int32_t* __restrict__ src, int 
 // NCH: channels per frame.  2 = the reference's int64 arrays (compress.c:482-511): sample-interleaved
 // low / high words, coded as two independent subframes (channel assignment 0b0001) one after the
 // other into the same bit ring.
+constexpr int kStereoSmall = 256;  // |low word| below this in the whole frame: the side + right trial is worth its analysis
+
 template <int MLO, int NCH = 1>
 #ifndef FA_K3_WAVES_ATTR
 #define FA_K3_WAVES_ATTR
@@ -570,8 +582,45 @@ FA_GLOBAL __global__ __launch_bounds__(64) FA_K3_WAVES_ATTR void encode_frames_k
     const uint4 fhe = a.hdr[f];
     const uint32_t fh_bits = 32u + ((fhe.w >> 8) & 0xFFu) + ((fhe.w >> 16) & 0xFFu) + (fhe.w >> 24) + 8u;
 
+    // Two-channel frames, stereo decision (libFLAC tries left/right, left/side, side/right, mid/side on the reference's
+    // two-channel path, compress.c:482-540; on (low word, high word) pairs only side/right can pay, tools/stereo_estimate.py):
+    // the first channel is coded as SIDE = low - high (assignment 0b1001, a 33-bit channel whose values are required to fit
+    // 32 bits, so only field widths change) when the high word is not zero throughout, every difference fits, the low word
+    // stays below kStereoSmall in magnitude (the gain is 10 % for values of a bit or two, 0.5 % at sigma 16 and nothing from
+    // sigma 128 on, while the trial doubles the analysis: profiles/r03_stereo_estimate.log), and the analysis estimates
+    // fewer bits for the side than for the low word.  Passes: 0 = low word, analysis only;
+    // 1 = side, analysis only; 2 = the winner, written as channel 0; 3 = the high word, written as channel 1.
+    int first_pass = (NCH == 2) ? 2 : 0;
+    if constexpr (NCH == 2) {
+        // (a probe of one pair per lane first: frames whose low word is not small -- nearly all frames of nearly all
+        // arrays -- are done after one load; the full scan runs only for the others)
+        auto pair_ok = [&](int lo_w, int hi_w) __attribute__((always_inline)) {
+            const int d = (int)((uint32_t)lo_w - (uint32_t)hi_w);
+            return (((lo_w ^ hi_w) & (lo_w ^ d)) >= 0)  // no signed overflow in low - high
+                   && (lo_w < kStereoSmall) && (lo_w > -kStereoSmall);
+        };
+        const int probe = (int)(((int64_t)lane * bs) >> 6);
+        const int2 pp = *reinterpret_cast<const int2*>(src + 2 * probe);
+        if (__all(pair_ok(pp.x, pp.y))) {
+            bool fits = true, rnz = false;
+#pragma unroll 4
+            for (int i = lane; i < bs; i += 64) {
+                const int2 pr = *reinterpret_cast<const int2*>(src + 2 * i);
+                fits = fits && pair_ok(pr.x, pr.y);
+                rnz = rnz || (pr.y != 0);
+            }
+            if (__all(fits) && __any(rnz)) first_pass = 0;
+        }
+    }
+    uint64_t est_left = 0;
+    bool use_side = false;
+    uint4 fhe_use = fhe;
 #pragma unroll 1
-    for (int ch = 0; ch < NCH; ++ch) {
+    for (int pass = first_pass; pass < ((NCH == 2) ? 4 : 1); ++pass) {
+    const int ch = (pass == 3) ? 1 : 0;
+    const bool dry = (NCH == 2) && (pass < 2);
+    const bool side = (NCH == 2) && (pass == 1 || (pass == 2 && use_side));
+    const uint4 fhe = fhe_use;  // (shadows the frame's entry: side + right frames take the table's second half)
     // writer state at the start of this subframe: a VERBATIM retry rewinds to it.  Everything not yet
     // flushed lies in block bf0 (one word per lane) and, when bf0 opens a ring cycle, the mirror word.
     const uint32_t pos0 = pos, bf0 = blocks_flushed;
@@ -582,7 +631,7 @@ FA_GLOBAL __global__ __launch_bounds__(64) FA_K3_WAVES_ATTR void encode_frames_k
     }
     // ---- P0: stage samples, wasted bits, constant test ---------------------------------
     for (int i = lane; i < kChunkStride; i += 64) smp[i] = 0;  // chunk -1 = zero history
-    const int32_t first = src[ch];
+    const int32_t first = side ? (int32_t)((uint32_t)src[0] - (uint32_t)src[1]) : src[ch];
     uint32_t orv = 0;
     bool narrow, is_const;
     const bool full = (bs == kMaxBlock) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
@@ -617,7 +666,8 @@ FA_GLOBAL __global__ __launch_bounds__(64) FA_K3_WAVES_ATTR void encode_frames_k
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int4 v = (ch == 0) ? make_int4(va[j].x, va[j].z, vb[j].x, vb[j].z) : make_int4(va[j].y, va[j].w, vb[j].y, vb[j].w);
+                    int4 v = (ch == 0) ? make_int4(va[j].x, va[j].z, vb[j].x, vb[j].z) : make_int4(va[j].y, va[j].w, vb[j].y, vb[j].w);
+                    if (side) v = make_int4(v.x - va[j].y, v.y - va[j].w, v.z - vb[j].y, v.w - vb[j].w);
                     orv |= (uint32_t)(v.x | v.y | v.z | v.w);
                     mn = min(min(mn, v.x), v.y);
                     mn = min(min(mn, v.z), v.w);
@@ -633,13 +683,13 @@ FA_GLOBAL __global__ __launch_bounds__(64) FA_K3_WAVES_ATTR void encode_frames_k
         narrow = (mn >= -(1 << 24)) && (mx < (1 << 24));  // every |x| <= 2^24: fixed-predictor errors fit 32-bit ints
     } else {
         bool alleq = true;
-        load_frame(src, bs, 0, smp, lane, &orv, &alleq, first, NCH, ch);
+        load_frame(src, bs, 0, smp, lane, &orv, &alleq, first, NCH, ch, side);
         is_const = __all(alleq);
         narrow = false;  // generic path: no narrow shortcut
     }
     orv = wave_or_u32(orv);
     const int wasted = orv ? (__ffs((int)orv) - 1) : 0;
-    const int bps = 32 - wasted;
+    const int bps = (side ? 33 : 32) - wasted;
     lds_fence();
     if (wasted) {
         for (int j = 0; j < nrows; ++j) {
@@ -662,10 +712,11 @@ FA_GLOBAL __global__ __launch_bounds__(64) FA_K3_WAVES_ATTR void encode_frames_k
 #pragma unroll
     for (int j = 0; j < ((MLO > 0) ? MLO : 1); ++j) qkeep[j] = 0;
 
+    uint64_t best_bits = verbatim_bits;  // estimated bits of the subframe the analysis settles on (the stereo decision compares them)
     if (is_const) {
         type = 0;
+        best_bits = 8 + (uint64_t)wasted + (uint64_t)bps;
     } else if (bs > 4) {
-        uint64_t best_bits = verbatim_bits;
 
         // ---- P2: fixed predictors 0..4 over the lane's chunk (exact in double) ---------
         double tot0 = 0.0, tot1 = 0.0, tot2 = 0.0, tot3 = 0.0, tot4 = 0.0;
@@ -1078,6 +1129,14 @@ FA_GLOBAL __global__ __launch_bounds__(64) FA_K3_WAVES_ATTR void encode_frames_k
     }
 
     FA_STAMP(8);
+    if (dry) {  // an analysis-only pass of the stereo decision: nothing is written
+        if (pass == 0) est_left = best_bits;
+        else {
+            use_side = best_bits < est_left;
+            if (use_side) fhe_use = a.hdr[a.nframes + f];
+        }
+        continue;
+    }
     // ---- emit (with one possible VERBATIM retry) ---------------------------------------
     for (int attempt = 0; attempt < 2; ++attempt) {
         // make the LDS image hold what this subframe type needs
@@ -1086,7 +1145,7 @@ FA_GLOBAL __global__ __launch_bounds__(64) FA_K3_WAVES_ATTR void encode_frames_k
         } else {
             if (lds_is_residual) {
                 uint32_t o2; bool e2;
-                load_frame(src, bs, wasted, smp, lane, &o2, &e2, first, NCH, ch);
+                load_frame(src, bs, wasted, smp, lane, &o2, &e2, first, NCH, ch, side);
                 lds_is_residual = false;
                 lds_fence();
             }
@@ -1140,22 +1199,23 @@ FA_GLOBAL __global__ __launch_bounds__(64) FA_K3_WAVES_ATTR void encode_frames_k
         // ---- preamble: frame header, subframe header, warm-up, LPC fields, residual header ----
         // One field (<= 32 bits) per lane, lane order = bit order; a scan of the field widths
         // gives every lane its bit position and the fields are ORed into the zeroed ring.
-        auto put_bits = [&](uint32_t P, uint32_t val, uint32_t nb) __attribute__((always_inline)) {
-            // val has nb (1..32) significant bits; place it at absolute bit position P
+        auto put_bits = [&](uint32_t P, uint64_t val, uint32_t nb) __attribute__((always_inline)) {
+            // val has nb (1..33: a side channel's sample fields) significant bits; place it at absolute bit position P
             const uint32_t off = P & 31u;
-            const uint64_t X = (uint64_t)val << (64u - nb - off);
+            const uint64_t X = val << (64u - nb - off);
             const uint32_t a0 = (P >> 3) & 0x7FCu;  // byte offset of the word inside the 2 KB ring
             atomicOr(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ring) + a0), (uint32_t)(X >> 32));
             atomicOr(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ring) + a0 + 4), (uint32_t)X);  // may be the mirror word
         };
         {
             const int tc = (type == 0) ? 0x00 : (type == 1) ? 0x01 : (type == 2) ? (0x08 | order) : (0x20 | (order - 1));
-            const uint32_t smask = (bps == 32) ? 0xffffffffu : ((1u << bps) - 1u);
+            const uint64_t smask = (1ull << bps) - 1ull;  // (bps <= 33; values are sign-extended into the field)
             const int nwarm = (type == 0) ? 1 : (type >= 2) ? order : 0;
             constexpr int kWarmLanes = (MLO > 4) ? MLO : 4;
             constexpr int kL_warm = 6, kL_lpc = kL_warm + kWarmLanes, kL_coef = kL_lpc + 1, kL_rice = kL_coef + ((MLO > 0) ? MLO : 1);
             static_assert(kL_rice < 64, "preamble fields must fit the wave");
-            uint32_t fv = 0, fnb = 0;
+            uint64_t fv = 0;
+            uint32_t fnb = 0;
             const bool fh = (ch == 0);  // the frame header precedes the first subframe only
             if (lane == 0) { if (fh) { fv = fhe.x; fnb = 32; } }
             else if (lane == 1) { if (fh) { fv = fhe.y; fnb = (fhe.w >> 8) & 0xFFu; } }
@@ -1167,7 +1227,7 @@ FA_GLOBAL __global__ __launch_bounds__(64) FA_K3_WAVES_ATTR void encode_frames_k
                 if (fh) { fv |= (fhe.w & 0xFFu) << 8; fnb = 16; }
             }
             else if (lane == 5) { if (wasted) { fv = 1; fnb = (uint32_t)wasted; } }  // unary: wasted-1 zeros, then 1
-            else if (lane < kL_lpc) { if (lane - kL_warm < nwarm) { fv = (uint32_t)smp[smp_idx(lane - kL_warm)] & smask; fnb = (uint32_t)bps; } }
+            else if (lane < kL_lpc) { if (lane - kL_warm < nwarm) { fv = (uint64_t)(int64_t)smp[smp_idx(lane - kL_warm)] & smask; fnb = (uint32_t)bps; } }
             else if (lane == kL_lpc) { if (type == 3) { fv = ((uint32_t)(precision - 1) << 5) | (uint32_t)shift; fnb = 9; } }
             else if (lane < kL_rice) {
                 if constexpr (MLO > 0) {
@@ -1207,7 +1267,7 @@ FA_GLOBAL __global__ __launch_bounds__(64) FA_K3_WAVES_ATTR void encode_frames_k
             }
         };
         if (type == 1) {
-            const uint32_t mask = (bps == 32) ? 0xffffffffu : ((1u << bps) - 1u);
+            const uint64_t mask = (1ull << bps) - 1ull;
             for (int j = 0; j < nrows; ++j) {
                 const int gb = kRow * j + 4 * lane;
                 const int4 rv = *reinterpret_cast<const int4*>(&smp[smp_idx(gb)]);
@@ -1220,7 +1280,7 @@ FA_GLOBAL __global__ __launch_bounds__(64) FA_K3_WAVES_ATTR void encode_frames_k
                 uint32_t p = pos + incl - lane_len;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const uint32_t v = (e < nvalid) ? ((uint32_t)rs[e] & mask) : 0u;
+                    const uint64_t v = (e < nvalid) ? ((uint64_t)(int64_t)rs[e] & mask) : 0ull;
                     put_bits(p, v, (uint32_t)bps);
                     p += (e < nvalid) ? (uint32_t)bps : 0u;
                 }
@@ -1395,7 +1455,7 @@ FA_GLOBAL __global__ __launch_bounds__(64) FA_K3_WAVES_ATTR void encode_frames_k
         fi.blocksize = bs;
         a.info[g * NCH + ch] = fi;
     }
-    }  // channel loop
+    }  // pass loop (one per channel; two-channel frames: up to two analysis-only passes first)
 
     // ---- tail: byte align, 16 zero bits for the CRC-16 (filled in by K5), final flush ----
     pos = (pos + 7u) & ~7u;

@@ -772,14 +772,17 @@ static int encode_device_begin(const int32_t* d_data, int nch, int64_t n_stream,
     {
         // frame header fields by frame number: tabulated on the host, cached on the device (per-device state)
         void* dp = nullptr;
-        rc = get_scratch(9, (size_t)pl.nf * sizeof(uint4) + 256, &dp);
+        const size_t ntab = (size_t)pl.nf * (nch == 2 ? 2 : 1);  // two-channel arrays: a second half with assignment side + right
+        rc = get_scratch(9, ntab * sizeof(uint4) + 256, &dp);
         if (rc) return rc;
         if (ds_->c_nf != pl.nf || ds_->c_B != a.B || ds_->c_tail != a.tail_bs || ds_->c_nch != nch || ds_->c_dp != dp ||
             ds_->c_epoch != ds_->scratch_epoch) {
-            ds_->h_hdr.resize((size_t)pl.nf);
-            for (int64_t f = 0; f < pl.nf; ++f)
+            ds_->h_hdr.resize(ntab);
+            for (int64_t f = 0; f < pl.nf; ++f) {
                 ds_->h_hdr[(size_t)f] = frame_header_entry((uint64_t)f, (f == pl.nf - 1) ? a.tail_bs : a.B, nch);
-            FA_HIP_TRY(hipMemcpyAsync(dp, ds_->h_hdr.data(), (size_t)pl.nf * sizeof(uint4), hipMemcpyHostToDevice, st));
+                if (nch == 2) ds_->h_hdr[(size_t)(pl.nf + f)] = frame_header_entry((uint64_t)f, (f == pl.nf - 1) ? a.tail_bs : a.B, nch, true);
+            }
+            FA_HIP_TRY(hipMemcpyAsync(dp, ds_->h_hdr.data(), ntab * sizeof(uint4), hipMemcpyHostToDevice, st));
             FA_HIP_TRY(hipStreamSynchronize(st));  // h_hdr is reused by the next call
             ds_->c_nf = pl.nf; ds_->c_B = a.B; ds_->c_tail = a.tail_bs; ds_->c_nch = nch; ds_->c_dp = dp; ds_->c_epoch = ds_->scratch_epoch;
         }

@@ -471,9 +471,12 @@ static void put_utf8(bitw_t *w, uint64_t v) {
     else { bw_put(w, 0xFC | (v >> 30), 8); bw_put(w, 0x80 | ((v >> 24) & 0x3F), 8); bw_put(w, 0x80 | ((v >> 18) & 0x3F), 8); bw_put(w, 0x80 | ((v >> 12) & 0x3F), 8); bw_put(w, 0x80 | ((v >> 6) & 0x3F), 8); bw_put(w, 0x80 | (v & 0x3F), 8); }
 }
 
-/* One subframe: samples xin[0], xin[stride], ... (stride 2 picks one channel of an interleaved pair) */
-static void encode_subframe(bitw_t *w, const int32_t *xin_s, int stride, int bs, const enc_params_t *P, const float *win,
-                            oracle_frame_info *info) {
+/* One subframe: samples xin[0], xin[stride], ... (stride 2 picks one channel of an interleaved pair).
+ * bps_base: 32, or 33 for a side channel (its values are required to fit 32 bits here, see encode_frame; only the field
+ * widths know about the 33rd bit).  w == NULL: analysis only.  Returns the estimated bits of the subframe the analysis
+ * settles on (the quantity candidates are compared by: encode_frame's stereo decision). */
+static uint64_t encode_subframe(bitw_t *w, const int32_t *xin_s, int stride, int bs, const enc_params_t *P, const float *win,
+                                oracle_frame_info *info, int bps_base) {
     static __thread int32_t xin[MAX_BLOCK], x[MAX_BLOCK], rfix[MAX_BLOCK], rlpc[MAX_BLOCK];
     for (int i = 0; i < bs; ++i) xin[i] = xin_s[(size_t)i * (size_t)stride];
 
@@ -483,7 +486,7 @@ static void encode_subframe(bitw_t *w, const int32_t *xin_s, int stride, int bs,
     int wasted = 0;
     if (orv) while (!((orv >> wasted) & 1)) wasted++;
     for (int i = 0; i < bs; ++i) x[i] = xin[i] >> wasted;
-    int bps = 32 - wasted;
+    int bps = bps_base - wasted;
 
     /* ---- candidates ---- */
     uint64_t verbatim_bits = 8 + (uint64_t)wasted + (uint64_t)bs * (uint64_t)bps;
@@ -496,11 +499,12 @@ static void encode_subframe(bitw_t *w, const int32_t *xin_s, int stride, int bs,
     rice_choice_t rc, rc_fix, rc_lpc;
     const int32_t *res = NULL;
     memset(&rc, 0, sizeof rc);
+    uint64_t best_bits = verbatim_bits;
 
     if (is_const) {
         type = 0;
+        best_bits = 8 + (uint64_t)wasted + (uint64_t)bps;
     } else if (bs > 4) {
-        uint64_t best_bits = verbatim_bits;
         /* fixed predictors, orders 0..4: total |e_k| over i >= k, invalid if any |e_k| > INT32_MAX */
         uint64_t tot[5] = {0, 0, 0, 0, 0};
         bool valid[5] = {true, true, true, true, true};
@@ -586,6 +590,8 @@ static void encode_subframe(bitw_t *w, const int32_t *xin_s, int stride, int bs,
         }
     }
 
+    if (!w) return best_bits;
+
     /* ---- subframe ---- */
     static const int type_code[4] = {0x00, 0x01, 0x08, 0x20};
     int tc = type_code[type];
@@ -595,13 +601,13 @@ static void encode_subframe(bitw_t *w, const int32_t *xin_s, int stride, int bs,
     bw_put(w, (uint64_t)tc, 6);
     bw_put(w, wasted ? 1 : 0, 1);
     if (wasted) { bw_zeros(w, (uint64_t)(wasted - 1)); bw_put(w, 1, 1); }
-    uint64_t mask = (bps == 32) ? 0xffffffffULL : ((1ULL << bps) - 1);
+    uint64_t mask = (1ULL << bps) - 1;  /* bps <= 33; the values are sign-extended into the field */
     if (type == 0) {
-        bw_put(w, (uint64_t)(uint32_t)x[0] & mask, (unsigned)bps);
+        bw_put(w, (uint64_t)(int64_t)x[0] & mask, (unsigned)bps);
     } else if (type == 1) {
-        for (int i = 0; i < bs; ++i) bw_put(w, (uint64_t)(uint32_t)x[i] & mask, (unsigned)bps);
+        for (int i = 0; i < bs; ++i) bw_put(w, (uint64_t)(int64_t)x[i] & mask, (unsigned)bps);
     } else {
-        for (int i = 0; i < order; ++i) bw_put(w, (uint64_t)(uint32_t)x[i] & mask, (unsigned)bps);
+        for (int i = 0; i < order; ++i) bw_put(w, (uint64_t)(int64_t)x[i] & mask, (unsigned)bps);
         if (type == 3) {
             bw_put(w, (uint64_t)(precision - 1), 4);
             bw_put(w, (uint64_t)shift, 5);
@@ -618,21 +624,49 @@ static void encode_subframe(bitw_t *w, const int32_t *xin_s, int stride, int bs,
         info->precision = (type == 3) ? precision : 0;
         info->blocksize = bs;
     }
+    return best_bits;
 }
 
 /* One frame of nch (1 or 2) channels; xin is sample-interleaved for nch == 2 (channel 0 = the low
- * 32 bits of the reference's int64 samples, utils.c:96-107; channels are coded independently,
- * channel assignment 0b0001) */
+ * 32 bits of the reference's int64 samples, utils.c:96-107).
+ *
+ * Stereo decision (libFLAC tries left/right, left/side, side/right and mid/side on the reference's two-channel path,
+ * compress.c:482-540).  On (low word, high word) pairs left/side and mid/side never pay: the side channel costs what
+ * the low word costs and the high word is the cheap one (tools/stereo_estimate.py).  side/right can: for small values
+ * of both signs the high word is 0 or -1 and side = low - high pulls the negative values one step towards zero.  So:
+ * the first channel is coded as SIDE (assignment 0b1001) when the high word is not zero throughout, every side value
+ * fits 32 bits (the 33rd bit then is a sign extension: only the field widths change), the low word stays below
+ * STEREO_SMALL in magnitude (the gain is 10 % for values of a bit or two, 0.5 % at sigma 16, nothing from sigma 128 on,
+ * while the trial doubles the analysis), and the analysis estimates fewer bits for it than for the low word; otherwise
+ * the channels are independent (0b0001). */
+#define STEREO_SMALL 256
 static void encode_frame(bitw_t *w, const int32_t *xin, int nch, int bs, uint64_t frame_no, const enc_params_t *P,
                          const float *win, oracle_frame_info *info) {
     size_t frame_start = (size_t)(w->nbits >> 3);
+    static __thread int32_t side[MAX_BLOCK];
+    bool use_side = false;
+    if (nch == 2) {
+        bool fits = true, right_zero = true, small = true;
+        for (int i = 0; i < bs; ++i) {
+            const int64_t d = (int64_t)xin[2 * i] - (int64_t)xin[2 * i + 1];
+            if (xin[2 * i + 1] != 0) right_zero = false;
+            if (xin[2 * i] >= STEREO_SMALL || xin[2 * i] <= -STEREO_SMALL) small = false;
+            if (d > 2147483647LL || d < -2147483648LL) { fits = false; break; }
+            side[i] = (int32_t)d;
+        }
+        if (fits && small && !right_zero) {
+            const uint64_t est_left = encode_subframe(NULL, xin, 2, bs, P, win, NULL, 32);
+            const uint64_t est_side = encode_subframe(NULL, side, 1, bs, P, win, NULL, 33);
+            use_side = est_side < est_left;
+        }
+    }
 
     /* ---- frame header (RFC 9639 9.1) ---- */
     int bsc = blocksize_code(bs);
     bw_put(w, 0xFFF8, 16);
     bw_put(w, (uint64_t)bsc, 4);
     bw_put(w, 9, 4);  /* 44.1 kHz: libFLAC default sample rate, the reference never sets one */
-    bw_put(w, (uint64_t)(nch - 1), 4);  /* mono / two independent channels */
+    bw_put(w, use_side ? 9u : (uint64_t)(nch - 1), 4);  /* mono / two independent channels / side + right */
     bw_put(w, 7, 3);  /* 32 bits per sample */
     bw_put(w, 0, 1);
     put_utf8(w, frame_no);
@@ -640,7 +674,10 @@ static void encode_frame(bitw_t *w, const int32_t *xin, int nch, int bs, uint64_
     else if (bsc == 7) bw_put(w, (uint64_t)(bs - 1), 16);
     bw_put(w, crc8(w->buf + frame_start, (size_t)(w->nbits >> 3) - frame_start), 8);
 
-    for (int c = 0; c < nch; ++c) encode_subframe(w, xin + c, nch, bs, P, win, info ? &info[c] : NULL);
+    for (int c = 0; c < nch; ++c) {
+        if (c == 0 && use_side) encode_subframe(w, side, 1, bs, P, win, info ? &info[c] : NULL, 33);
+        else encode_subframe(w, xin + c, nch, bs, P, win, info ? &info[c] : NULL, 32);
+    }
 
     bw_align(w);
     bw_reserve(w, 16);

@@ -1200,3 +1200,40 @@ def test_single_pass_capacity_smaller_than_worst_case(fa, oracle):
         assert rc == 1
         assert bool((buf[cap:] == 0xA5).all()), "bytes behind the caller's buffer were written"
 
+
+def test_int64_side_right_decision(fa, oracle):
+    """The reference's two-channel path lets libFLAC choose a stereo assignment per frame (compress.c:482-540).  The
+    encoder here codes the first channel as SIDE (low word - high word, assignment 0b1001) when the low word is small, the
+    high word is not zero throughout and the analysis estimates fewer bits for the side -- the one assignment that pays
+    on (low word, high word) pairs.  HIP bytes must equal the oracle's, frames of both assignments must occur, and the
+    throughput decoder, the oracle's decoder and the independent pure-Python decoder must all return the input."""
+    import torch
+
+    from tests.golden import pyflac
+
+    rng = np.random.default_rng(17)
+    n = 13000
+    x = np.empty((4, n), dtype=np.int64)
+    x[0] = rng.integers(-3, 4, n)                      # both signs, tiny: side + right wins
+    x[1] = rng.integers(0, 6, n)                       # high word zero throughout: no trial, independent channels
+    x[2] = np.rint(rng.normal(0, 40, n))               # small enough for the trial
+    x[3] = np.rint(rng.normal(0, 5000, n))             # low word too large: independent channels
+    for level in (0, 5, 8):
+        blob_o, st_o, nb_o = oracle.encode_i64(x, level)
+        comp, st, nb = fa.encode_flac_device(torch.from_numpy(x).cuda(), level=level)
+        assert np.array_equal(comp.cpu().numpy(), blob_o), level
+        assert np.array_equal(st.cpu().numpy(), st_o) and np.array_equal(nb.cpu().numpy(), nb_o)
+        y = fa.decode_flac_device(comp, st, nb, n, is_int64=True).cpu().numpy()
+        assert np.array_equal(y, x)
+        assert np.array_equal(oracle.decode_i64(blob_o, st_o, nb_o, n), x)
+        kinds = set()
+        for i in range(4):
+            stream = bytes(blob_o[st_o[i] : st_o[i] + nb_o[i]])
+            out, sinfo = pyflac.decode_stream(stream)  # (sample-interleaved low / high words)
+            assigns = [fr["assignment"] for fr in sinfo["frames"]]
+            lo, hi = np.asarray(out[0::2], dtype=np.int64), np.asarray(out[1::2], dtype=np.int64)
+            assert np.array_equal((hi << 32) | (lo & 0xFFFFFFFF), x[i]), (level, i)
+            kinds |= {(i, a) for a in assigns}
+        assert {a for (i, a) in kinds if i == 0} == {9}, "tiny values of both signs: every frame side + right"
+        assert {a for (i, a) in kinds if i in (1, 3)} == {1}, "no trial where the high word is zero or the low word large"
+

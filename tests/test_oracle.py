@@ -252,3 +252,29 @@ def test_quantization_rules(oracle):
     st = np.float32(x[0, k] - off[0])
     pr = np.float32(g[0] * st)
     assert i[0, k] == int(np.float64(pr) + (0.5 if st >= 0 else -0.5))
+
+
+def test_int64_side_right_streams_read_by_the_independent_decoder(oracle):
+    """Two-channel streams whose first channel is coded as SIDE (assignment 0b1001, a 33-bit channel): the oracle encoder
+    chooses it for small values of both signs (compress.c:482-540 leaves the choice to libFLAC); the pure-Python decoder
+    of tests/golden/pyflac.py -- no code shared with the oracle -- and the oracle's own decoder return the input."""
+    from tests.golden import pyflac
+
+    rng = np.random.default_rng(17)
+    n = 9000
+    x = np.empty((3, n), dtype=np.int64)
+    x[0] = rng.integers(-3, 4, n)
+    x[1] = rng.integers(0, 6, n)           # high word zero: independent channels
+    x[2] = np.rint(rng.normal(0, 5000, n))  # low word too large for the trial: independent channels
+    for level in (0, 5, 8):
+        blob, st, nb = oracle.encode_i64(x, level)
+        assert np.array_equal(oracle.decode_i64(blob, st, nb, n), x)
+        assert np.array_equal(oracle.decode_i64(blob, st, nb, n, 4000, 4600), x[:, 4000:4600])
+        seen = {}
+        for i in range(3):
+            out, info = pyflac.decode_stream(bytes(blob[st[i] : st[i] + nb[i]]))
+            lo, hi = np.asarray(out[0::2], dtype=np.int64), np.asarray(out[1::2], dtype=np.int64)
+            assert np.array_equal((hi << 32) | (lo & 0xFFFFFFFF), x[i])
+            seen[i] = {fr["assignment"] for fr in info["frames"]}
+        assert seen == {0: {9}, 1: {1}, 2: {1}}
+
