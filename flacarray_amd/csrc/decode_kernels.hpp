@@ -540,7 +540,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define FA_K7_NT 1  // whole-tile stores bypass the caches (streaming output): -1.5 % in the same-box A/B (r03i)
 #endif
 #ifndef FA_K7_X
-#define FA_K7_X 0  // timing experiments only (results are wrong): 1 = no prediction, 2 = no global stores, 4 = no tile write
+#define FA_K7_X 0  // timing experiments only (results are wrong): 1 = no prediction, 2 = no global stores, 4 = no tile write,
+                   // 8 = no chunk loads in the sample loop
 #endif
 constexpr int kTileW = FA_TILE_W;                // samples per lane between two cooperative stores
 constexpr int kTileG = kTileW / 4;               // 16-byte groups per row
@@ -588,7 +589,11 @@ __device__ __forceinline__ Chunk chunk_fetch(const uint8_t* cbase, const uint8_t
 #pragma unroll
     for (int v = 0; v < kChunkBytes / 16; ++v) {
         c.d[v] = make_uint4(0, 0, 0, 0);
+#if (FA_K7_X & 8)  // timing experiment: no chunk loads in the sample loop (a bit pattern of short codes instead)
+        c.d[v] = make_uint4(0x55555555u ^ ci, 0x55555555u, 0x55555555u, 0x55555555u);
+#else
         if (q + 16 * v + 16 <= lim16) c.d[v] = *reinterpret_cast<const uint4*>(q + 16 * v);
+#endif
     }
     return c;
 }
