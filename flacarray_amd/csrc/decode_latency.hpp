@@ -61,39 +61,65 @@ __device__ __forceinline__ uint32_t lat_code_len(const uint32_t* img, uint32_t p
     return q + (uint32_t)__clz((int)A) + 1u + k;
 }
 
-constexpr int kLatResPad = 16;  // the predictor loops work in whole groups: room behind the last sample of a 4096 block
+constexpr int kLatResPad = 48;  // the predictor loops work in whole blocks of 16 and look one block ahead: room behind the last sample of a 4096 block
 
-template <int MO>
-__device__ __forceinline__ void lat_restore_lpc(int32_t* res, const double* coef, int order, int hi) {
-    // every lane runs the same recurrence on the same LDS words (broadcast reads); one lane stores
-    double c[MO], h[MO];
+// The LPC recurrence of one frame -- serial by nature -- with the TAPS spread over the lanes of a row.
+//
+// Transposed form: a new sample x_n is added, times c_j, into the running sum of sample n + 1 + j (j = 0 .. order - 1);
+// a sample's sum starts as its residual and is complete when sample n - 1 has been added, x = floor(sum): the residual
+// seeds the sum, x = floor(r + sum c_j x_j 2^-shift) = r + floor(sum ...), every partial sum being an exact multiple of
+// 2^-shift below 2^53 (coefficients < 2^15, samples < 2^32, at most 12 terms) -- so the order of the terms is free and
+// the result is bit-identical to K7's.  Lane m of a 16-lane row owns the sums of samples base + m, base + 16 + m, ...;
+// at step k the row's lane k holds a complete sum, `v_floor_f64_dpp row_newbcast:k` floors it and hands it to all 16
+// lanes in one instruction, and ONE `v_fmac_f64` adds it to the 16 sums with the lane's own coefficient for that
+// distance (sixteen rotated copies of the coefficient vector, zero beyond the order, are kept in registers: lane m,
+// step k: c[(m - k - 1) mod 16]).  Two vector instructions per sample instead of order + 2; the chain from sample to
+// sample is those two.  Every four steps the four lanes that have completed hand over their samples and take the
+// residuals of the samples 16 further on -- early enough for orders up to 12, whose first term for a sample arrives
+// 12 steps before it, and late enough that the lane's value has been broadcast; in between such a lane only adds
+// zeros.  The four rows of the wave do the same work on the same data.  (A lone wave issues one vector instruction per
+// ~6 cycles, profiles/r01k_valu_rates.txt: 116 us of an order-8 frame's 182 were the predictor with order + 4
+// instructions per sample on every lane alike.)
+template <int K>
+__device__ __forceinline__ double lat_floor_bcast(double a) {
+    double x;
+    // (two wait states between the vector instruction that wrote `a` and a DPP read of it)
+    asm volatile("s_nop 1\n\tv_floor_f64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(x) : "v"(a), "n"(K));
+    return x;
+}
+
+__device__ __forceinline__ void lat_restore_lpc(int32_t* res, const double* coef16, int order, int hi) {
+    const int m = threadIdx.x & 15;
+    double cr[16];
 #pragma unroll
-    for (int j = 0; j < MO; ++j) {
-        c[j] = (j < order) ? coef[j] : 0.0;
-        h[j] = (j < order) ? (double)res[order - 1 - j] : 0.0;  // h[j] = x[n - 1 - j]
+    for (int k = 0; k < 16; ++k) cr[k] = coef16[(m - k - 1) & 15];  // (zero from `order` on)
+    int base = order;
+    // the first 16 sums: residual + the terms of the warm-up samples
+    double acc = (double)res[base + m];
+    for (int j = 0; j < order; ++j) {
+        const int xi = base + m - 1 - j;  // >= 0: j < order = base
+        if (xi < base) acc = __builtin_fma(coef16[j], (double)res[xi], acc);
     }
-    const int lane = threadIdx.x;
-    // groups of MO samples: the history rotates through the registers by renaming, not by moves; a group's residuals
-    // are fetched together before its first sample is computed (a read inside the chain would put the LDS latency on
-    // it: 0.5 ms per frame), and the last group may run past `hi` into values nobody reads
-    for (int i = order; i < hi; i += MO) {
-        int32_t r[MO], o[MO];
-#pragma unroll
-        for (int u = 0; u < MO; ++u) r[u] = res[i + u];
-#pragma unroll
-        for (int u = 0; u < MO; ++u) {
-            double sum = 0.0;
-            // x[n-1-j] lives in h[(j - u) mod MO]: the newest sample (j = 0) enters last
-#pragma unroll
-            for (int j = MO - 1; j >= 0; --j) sum = __builtin_fma(c[j], h[(j + MO - u) % MO], sum);
-            const double xd = (double)r[u] + fa_floor(sum);
-            h[(2 * MO - 1 - u) % MO] = xd;  // overwrites x[n - MO]; it is x[n - 1] for the next sample
-            o[u] = (int32_t)xd;
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int u = 0; u < MO; ++u) res[i + u] = o[u];
-        }
+    const bool g0 = (m >> 2) == 0, g1 = (m >> 2) == 1, g2 = (m >> 2) == 2, g3 = (m >> 2) == 3;
+    for (; base < hi; base += 16) {  // (the last block and the look-ahead may run past `hi` into values nobody reads)
+        const double rn = (double)res[base + 16 + m];
+        int32_t out = 0;
+        auto hand_over = [&](bool mine) __attribute__((always_inline)) {
+            const int32_t t = (int32_t)fa_floor(acc);
+            out = mine ? t : out;
+            acc = mine ? rn : acc;
+        };
+#define FA_LAT_STEP(K) { const double x = lat_floor_bcast<K>(acc); acc = __builtin_fma(x, cr[K], acc); }
+        FA_LAT_STEP(0) FA_LAT_STEP(1) FA_LAT_STEP(2) FA_LAT_STEP(3)
+        hand_over(g0);
+        FA_LAT_STEP(4) FA_LAT_STEP(5) FA_LAT_STEP(6) FA_LAT_STEP(7)
+        hand_over(g1);
+        FA_LAT_STEP(8) FA_LAT_STEP(9) FA_LAT_STEP(10) FA_LAT_STEP(11)
+        hand_over(g2);
+        FA_LAT_STEP(12) FA_LAT_STEP(13) FA_LAT_STEP(14) FA_LAT_STEP(15)
+        hand_over(g3);
+#undef FA_LAT_STEP
+        res[base + m] = out;  // (the four rows store the same 16 values)
     }
 }
 
@@ -101,7 +127,7 @@ template <bool F32>
 __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInline inl, int* fallback) {
     __shared__ __attribute__((aligned(16))) uint32_t img[kLatImgWords + kLatPadWords];
     __shared__ __attribute__((aligned(16))) int32_t res[kLatMaxBlock + kLatResPad];
-    __shared__ double coef_s[12];
+    __shared__ double coef_s[16];  // pre-scaled coefficients, zero from the order on
     const int lane = threadIdx.x;
     const int64_t task = blockIdx.x;
     if (task >= a.n_tasks) return;
@@ -258,6 +284,7 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
             shift = gets(5);
             if (prec == 16 || shift < 0) bad = true;
             const double scale = bitsd((uint64_t)(1023 - (shift < 0 ? 0 : shift)) << 52);
+            if (lane < 16) coef_s[lane] = 0.0;
             for (int j = 0; j < order; ++j) {
                 const double v = (double)gets(prec) * scale;  // pre-scaled by 2^-shift (exact, as in K7)
                 if (lane == 0) coef_s[j] = v;
@@ -392,9 +419,7 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
         // ---- predictor ----
         if ((FA_LAT_X & 1) != 0) {
         } else if (is_lpc) {
-            if (order <= 4) lat_restore_lpc<4>(res, coef_s, order, hi);
-            else if (order <= 8) lat_restore_lpc<8>(res, coef_s, order, hi);
-            else lat_restore_lpc<12>(res, coef_s, order, hi);
+            lat_restore_lpc(res, coef_s, order, hi);
         } else if (order > 0) {
             // FIXED: wrapping 32-bit arithmetic is exact here (every sample fits its 32 bits; RFC 9639 9.2.5)
             uint32_t x1 = order >= 1 ? (uint32_t)res[order - 1] : 0u, x2 = order >= 2 ? (uint32_t)res[order - 2] : 0u;
@@ -427,13 +452,13 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
 
     // ---- store [lo, hi) ----
     const int64_t row0 = out_off + (fstart - sl_first);
+    auto sample = [&](int i) __attribute__((always_inline)) -> int32_t { return (int32_t)((uint32_t)res[i] << wasted); };
     if constexpr (F32) {
         const float og = a.offsets[s];
         const float cf = (float)(1.0 / (double)a.gains[s]);  // utils.c:361
-        for (int i = lo + lane; i < hi; i += 64)
-            a.out_f32[row0 + i] = __fadd_rn(og, __fmul_rn(cf, (float)(int32_t)((uint32_t)res[i] << wasted)));  // utils.c:364
+        for (int i = lo + lane; i < hi; i += 64) a.out_f32[row0 + i] = __fadd_rn(og, __fmul_rn(cf, (float)sample(i)));  // utils.c:364
     } else {
-        for (int i = lo + lane; i < hi; i += 64) a.out_i32[row0 + i] = (int32_t)((uint32_t)res[i] << wasted);
+        for (int i = lo + lane; i < hi; i += 64) a.out_i32[row0 + i] = sample(i);
     }
 }
 
