@@ -134,7 +134,9 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
     // reason bits (diagnostics only; any non-zero value makes the host repeat the launch with K7):
     // 1 geometry / frame does not fit, 2 header, 4 subframe kind or order, 8 residual layout, 16 no parse, 32 overrun
     auto give_up = [&](int why) __attribute__((always_inline)) {
-        if (lane == 0) atomicOr(fallback, why);
+        // (a plain store: the word may live in pinned host memory, and all the host asks is "non-zero?"; with several
+        // frames giving up the diagnostic shows one of their reasons)
+        if (lane == 0) *reinterpret_cast<volatile int*>(fallback) = why;
     };
 
     // ---- task (wave-uniform) ----
@@ -342,7 +344,10 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
                 const uint32_t smin = (32u + kSegPerK * k) * avg_bits;
                 if (S < smin) S = smin;
                 const uint32_t lim = frame_end_bits + 64u;
-                // phase A: code lengths through two segments
+                // phase A: code lengths through two segments.  (Both phases read the image through lat_win, two LDS words per
+                // code.  A register window of four words per lane, refilled one word per 32 bits of progress and two words
+                // ahead, was built and measured: 93 us instead of 64 for a FIXED-0 frame -- the refill's divergent shifts
+                // cost a lone wave more issue slots than the LDS round trips it saves.)
                 uint32_t q0 = b + (uint32_t)lane * S;
                 const uint32_t lim1 = q0 + S, lim2 = lim1 + S;
                 // (a parse that finds no further stop bit has run past the frame's last code: it ends there, with the

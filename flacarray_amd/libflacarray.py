@@ -11,6 +11,7 @@ The int64 / float64 twins (`wrap_encode_i64[_threaded]` :407/:468, `wrap_decode_
 same kernels.
 """
 import ctypes
+import sys
 import weakref
 
 import numpy as np
@@ -622,8 +623,6 @@ class DeviceDecodeIndex:
             self._h = ctypes.c_void_p(None)
 
     def __del__(self):
-        import sys
-
         if sys is None or sys.is_finalizing():  # the HIP runtime may be gone already: the process ends anyway
             return
         try:
