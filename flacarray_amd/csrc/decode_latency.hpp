@@ -31,6 +31,20 @@ namespace fa {
 #ifndef FA_LAT_X
 #define FA_LAT_X 0  // timing experiments only (wrong results): 1 = no predictor, 2 = one parse round only, 4 = no value pass
 #endif
+#ifndef FA_LAT_SEG_BASE
+#define FA_LAT_SEG_BASE 32  // shortest segment of the speculative parse: FA_LAT_SEG_BASE + FA_LAT_SEG_PER_K * k codes
+#endif
+#ifndef FA_LAT_SEG_PER_K
+#define FA_LAT_SEG_PER_K 1
+#endif
+#ifndef FA_LAT_STAMPS
+#define FA_LAT_STAMPS 0  // diagnostic build: lane 0 of task 0 prints where its time went (100 MHz ticks), tools/lat_time.py
+#endif
+#if FA_LAT_STAMPS
+#define FA_LAT_STAMP(i) do { lat_t[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FA_LAT_STAMP(i) do { } while (0)
+#endif
 constexpr int kLatMaxBlock = 4096;
 constexpr int kLatImgWords = 4416;  // 17664 bytes: a 4096-sample VERBATIM frame at 32 bits per sample is 16384 + headers
 constexpr int kLatPadWords = 8;     // zero words behind the image: speculative parses may look past the frame
@@ -42,10 +56,21 @@ struct LatInline {
     int32_t n;
 };
 
+// The image is kept in REVERSE word order (word w of the frame at img[kLatTop - w]): the two words of a window then
+// come out of one ds_read2_b32 as the low and high half of a 64-bit register pair in the order the shift wants them
+// (forward order costs a swap and its wait state per window, and a window is read for every code of the parse).
+constexpr uint32_t kLatTop = (uint32_t)(kLatImgWords + kLatPadWords - 1);
 __device__ __forceinline__ uint32_t lat_win(const uint32_t* img, uint32_t pos) {  // bits [pos, pos + 32)
     uint32_t wi = pos >> 5;
-    wi = wi < (uint32_t)(kLatImgWords + kLatPadWords - 2) ? wi : (uint32_t)(kLatImgWords + kLatPadWords - 2);
-    const uint64_t v = ((uint64_t)img[wi] << 32) | img[wi + 1];
+    wi = wi < kLatTop - 1u ? wi : kLatTop - 1u;  // (zero words behind the frame)
+    const uint32_t* const q = img + (kLatTop - 1u - wi);  // q[0] = word wi + 1, q[1] = word wi
+    const uint64_t v = ((uint64_t)q[1] << 32) | q[0];
+    return (uint32_t)((v << (pos & 31)) >> 32);
+}
+// the same for positions known to lie inside the image (the walks of the parse stop at the frame's end)
+__device__ __forceinline__ uint32_t lat_win_in(const uint32_t* img, uint32_t pos) {
+    const uint32_t* const q = img + (kLatTop - 1u - (pos >> 5));
+    const uint64_t v = ((uint64_t)q[1] << 32) | q[0];
     return (uint32_t)((v << (pos & 31)) >> 32);
 }
 
@@ -139,6 +164,11 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
         if (lane == 0) *reinterpret_cast<volatile int*>(fallback) = why;
     };
 
+#if FA_LAT_STAMPS
+    uint64_t lat_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t lat_rounds = 0, lat_parts = 0, lat_segs = 0, lat_codes = 0, lat_k = 0, lat_S = 0;
+#endif
+    FA_LAT_STAMP(0);
     // ---- task (wave-uniform) ----
     int64_t s, f, sl_first, sl_last, out_off;
     if (inl.n > 0) {
@@ -164,19 +194,34 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
 
     // ---- frame image: coalesced 16-byte loads, big-endian words ----
     {
-        const uint8_t* const lim16 = reinterpret_cast<const uint8_t*>((reinterpret_cast<uintptr_t>(a.blob + a.blob_bytes) + 15) & ~(uintptr_t)15);
+        // (the frame lies inside the blob and the blob starts on a 16-byte boundary: every piece can be read whole.)
+        // Eight loads in flight per lane: a loop of load / wait / store pays the memory latency once per 1 KB, ~10 times
+        // per frame of the benchmark data.
         const uint32_t pieces = (nbytes + 15u) >> 4;
-        for (uint32_t i = lane; i < pieces; i += 64) {
-            const uint8_t* q = a.blob + base + 16 * (int64_t)i;
-            uint4 d = make_uint4(0, 0, 0, 0);
-            if (q + 16 <= lim16) d = *reinterpret_cast<const uint4*>(q);
-            uint4 o;
-            o.x = __builtin_bswap32(d.x); o.y = __builtin_bswap32(d.y); o.z = __builtin_bswap32(d.z); o.w = __builtin_bswap32(d.w);
-            *reinterpret_cast<uint4*>(&img[4 * i]) = o;
+        const uint8_t* const q0 = a.blob + base;
+        for (uint32_t i0 = 0; i0 < pieces; i0 += 512) {
+            uint4 d[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                uint32_t i = i0 + 64u * (uint32_t)t + (uint32_t)lane;
+                i = i < pieces ? i : pieces - 1u;  // (unconditional loads: a predicated one would be waited for on its own)
+                d[t] = *reinterpret_cast<const uint4*>(q0 + 16 * (int64_t)i);
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const uint32_t i = i0 + 64u * (uint32_t)t + (uint32_t)lane;
+                if (i < pieces) {
+                    uint4 o;
+                    // words 4 i .. 4 i + 3 go to img[kLatTop - 4 i - 3 .. kLatTop - 4 i], highest word first
+                    o.w = __builtin_bswap32(d[t].x); o.z = __builtin_bswap32(d[t].y); o.y = __builtin_bswap32(d[t].z); o.x = __builtin_bswap32(d[t].w);
+                    *reinterpret_cast<uint4*>(&img[kLatTop - 3u - 4u * i]) = o;
+                }
+            }
         }
-        for (uint32_t i = 4 * pieces + lane; i < (uint32_t)(kLatImgWords + kLatPadWords); i += 64) img[i] = 0;
+        for (uint32_t i = 4 * pieces + lane; i < (uint32_t)(kLatImgWords + kLatPadWords); i += 64) img[kLatTop - i] = 0;
     }
     __syncthreads();
+    FA_LAT_STAMP(1);
 
     // ---- uniform bit reader ----
     uint32_t pos = skip * 8u;
@@ -299,6 +344,7 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
         if (bad || method > 1 || (po > 0 && (ps << po) != bs) || ps < order) { give_up(8); return; }
         __syncthreads();
 
+        FA_LAT_STAMP(2);
         // ---- residual: partitions in turn, the codes of a partition in parallel ----
         uint32_t idx0 = (uint32_t)order;           // sample index of the next residual
         uint32_t left_in_frame = (uint32_t)(bs - order);
@@ -327,6 +373,9 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
             if (idx0 + want > (uint32_t)hi) want = (uint32_t)hi - idx0;
             const bool last_partition_needed = (want < n);
             uint32_t b = pos, todo = want;
+#if FA_LAT_STAMPS
+            lat_parts++; lat_codes += want;
+#endif
             while (todo > 0) {
                 // segment length: this partition's share of the frame's remaining bits, spread over 64 lanes; at least
                 // a few codes long so that a parse started in the middle of a code has room to fall in step
@@ -335,74 +384,121 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
                 uint32_t S = (uint32_t)(est >> 6) + 1u;
                 // A parse that starts inside a code falls in step with the true one when the two land on the same bit;
                 // their distance does a random walk whose steps are the differences of the unary parts: a few codes at
-                // k = 0, around a hundred at k = 16 (noise-like data).  Segments shorter than that mostly fail their
-                // verification and the partition takes many rounds; much longer ones leave lanes without work.  Whole-frame
-                // reads of the benchmark data (k = 16..17, profiles/r03_reads.md), segments of at least 32 + c k codes:
-                // c = 0: 125 us (FIXED 0) / 197 us (LPC 8), c = 4: 64 / 185, c = 8: 99 / 221, c = 14: 154 / 274.
-                constexpr uint32_t kSegPerK = 4;
+                // k = 0, around a hundred at k = 16 (noise-like data).  With ONE segment of continuation per lane a lane
+                // that had not fallen in step inside its own segment ended the round, and segments had to be that long
+                // (32 + 4 k codes: 64 us for a FIXED-0 frame of the benchmark data, k = 16..17; 32 codes: 125 us, 32 + 14 k:
+                // 154 us, profiles/r03_reads.md).  With TWO segments of continuation (below) the neighbour's parse carries
+                // the truth across such a lane and the frame's own spread over the 64 lanes (64 codes each) resolves in
+                // one round: minimum 32 + k codes, 53 us (32 + 4 k with the third walk: 75 us).
+                constexpr uint32_t kSegBase = FA_LAT_SEG_BASE, kSegPerK = FA_LAT_SEG_PER_K;
                 const uint32_t avg_bits = rem_bits / (left_in_frame ? left_in_frame : 1u) + 1u;
-                const uint32_t smin = (32u + kSegPerK * k) * avg_bits;
+                const uint32_t smin = (kSegBase + kSegPerK * k) * avg_bits;
                 if (S < smin) S = smin;
                 const uint32_t lim = frame_end_bits + 64u;
-                // phase A: code lengths through two segments.  (Both phases read the image through lat_win, two LDS words per
-                // code.  A register window of four words per lane, refilled one word per 32 bits of progress and two words
-                // ahead, was built and measured: 93 us instead of 64 for a FIXED-0 frame -- the refill's divergent shifts
-                // cost a lone wave more issue slots than the LDS round trips it saves.)
+                // phase A: code lengths through the lane's own segment and the two after it.  (Both phases read the image
+                // through lat_win, two LDS words per code.  A register window of four words per lane, refilled one word
+                // per 32 bits of progress and two words ahead, was built and measured: 93 us instead of 64 for a FIXED-0
+                // frame -- the refill's divergent shifts cost a lone wave more issue slots than the LDS round trips it saves.)
                 uint32_t q0 = b + (uint32_t)lane * S;
-                const uint32_t lim1 = q0 + S, lim2 = lim1 + S;
+                const uint32_t lim1 = q0 + S;
                 // (a parse that finds no further stop bit has run past the frame's last code: it ends there, with the
                 // sentinel as its exit -- whatever lies behind the last code is cut off by the code count below)
-                uint32_t cx = 0, cy = 0;
+                uint32_t xs[3], cs[3];  // exit from the lane's own segment and the two after it; codes counted in each
                 bool ended = false;
-                while (q0 < lim1) {
-                    const uint32_t len = lat_code_len(img, q0, k, lim);
-                    if (len == 0) { ended = true; break; }
-                    q0 += len; cx++;
+                // (the walks are written with wave-uniform control: every lane takes every step, those that are done just do
+                // not advance.  Per-lane loops cost ~50 instructions per code, two thirds of them exec-mask bookkeeping --
+                // and a lone wave pays ~6 cycles for each; this form takes ~20.)
+#pragma unroll
+                for (int w = 0; w < 3; ++w) {
+                    const uint32_t limw = lim1 + (uint32_t)w * S;
+                    uint32_t c = 0;
+                    for (;;) {
+                        ended = ended || q0 >= lim;  // (behind the frame: zeros, no code)
+                        const bool go = !ended && q0 < limw;
+                        if (__builtin_amdgcn_ballot_w64(go) == 0) break;
+                        const uint32_t A = lat_win_in(img, ended ? 0u : q0);
+                        uint32_t len = (uint32_t)__clz((int)A) + 1u + k;
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(go && A == 0) != 0, 0)) {  // 32 zeros or more somewhere: the general reader
+                            if (go) {
+                                len = lat_code_len(img, q0, k, lim);
+                                if (len == 0) ended = true;
+                            }
+                        }
+                        const bool adv = go && !ended;
+                        q0 += adv ? len : 0u;
+                        c += adv ? 1u : 0u;
+                    }
+                    xs[w] = ended ? 0xffffffffu : q0;
+                    cs[w] = c;
                 }
-                const uint32_t x = ended ? 0xffffffffu : q0;
-                while (!ended && q0 < lim2) {
-                    const uint32_t len = lat_code_len(img, q0, k, lim);
-                    if (len == 0) { ended = true; break; }
-                    q0 += len; cy++;
+                // Verification.  Two parses that ever stand on the same bit stay together, and lane 0's is the true one.
+                // Lane l's parse is TRUE at the entry of segment l + 1 if it left its own segment where a true parse of
+                // lane l - 1 or l - 2 did (t1), at the entry of segment l + 2 if it was true before or left segment l + 1
+                // where lane l - 1's true parse did (t2).  With two segments of continuation a lane that has not fallen in
+                // step within its own segment does not end the round: its neighbour's parse carries the truth across.
+                const uint32_t x1p1 = (uint32_t)__shfl_up((int)xs[0], 1, 64), c2p1 = (uint32_t)__shfl_up((int)cs[1], 1, 64);
+                const uint32_t x2p1 = (uint32_t)__shfl_up((int)xs[1], 1, 64), x3p1 = (uint32_t)__shfl_up((int)xs[2], 1, 64);
+                const uint32_t x2p2 = (uint32_t)__shfl_up((int)xs[1], 2, 64), x3p2 = (uint32_t)__shfl_up((int)xs[2], 2, 64);
+                const uint32_t c3p2 = (uint32_t)__shfl_up((int)cs[2], 2, 64);
+                const uint64_t mA = __ballot(lane >= 1 && xs[0] == x2p1);  // joins lane l-1 at the entry of segment l+1
+                const uint64_t mB = __ballot(lane >= 2 && xs[0] == x3p2);  // joins lane l-2 there
+                const uint64_t mC = __ballot(lane >= 1 && xs[1] == x3p1);  // joins lane l-1 at the entry of segment l+2
+                if (__builtin_amdgcn_readfirstlane((int)cs[0]) == 0) { give_up(16); return; }  // not one code where one must be: damaged (K7 reports it)
+                uint64_t t1 = 1, t2 = 1;
+                for (int l = 1; l < 64; ++l) {
+                    const uint64_t p1 = (t2 >> (l - 1)) & 1u, p2 = (l >= 2) ? ((t2 >> (l - 2)) & 1u) : 0u;
+                    if (!(p1 | p2)) break;  // no true parse in the two lanes before: nothing reaches further
+                    const uint64_t b1 = ((p1 & (mA >> l)) | (p2 & (mB >> l))) & 1u;
+                    const uint64_t b2 = (b1 | (p1 & (mC >> l))) & 1u;
+                    t1 |= b1 << l;
+                    t2 |= b2 << l;
                 }
-                const uint32_t y = ended ? 0xffffffffu : q0;
-                // verification chain
-                const uint32_t y_prev = (uint32_t)__shfl_up((int)y, 1, 64);
-                const uint32_t x_prev = (uint32_t)__shfl_up((int)x, 1, 64);
-                const uint32_t cy_prev = (uint32_t)__shfl_up((int)cy, 1, 64);
-                // lane l is verified iff lanes 0..l-1 are and it left its segment where the true parse does
-                const bool link = (lane == 0) || (x == y_prev);
-                const uint64_t chain = __ballot(link);
-                const int L = (chain == ~0ull) ? 64 : __builtin_ctzll(~chain);  // verified lanes: 0 .. L-1 (L >= 1)
-                if (__builtin_amdgcn_readfirstlane((int)cx) == 0) { give_up(16); return; }  // not one code where one must be: damaged (K7 reports it)
-                // segment m <= min(L, 63) has a known entry and code count (from lane m - 1's continued parse)
-                const int nseg = (L < 64) ? (L + 1) : 64;
+                // segment m is resolved (true entry and code count known) by lane m-1 true at its entry, or by lane m-2
+                const uint64_t by1 = t1 << 1, by2 = t2 << 2;
+                const uint64_t resolved = 1ull | by1 | by2;
+                const int nseg = (resolved == ~0ull) ? 64 : __builtin_ctzll(~resolved);  // segments 0 .. nseg-1
+#if FA_LAT_STAMPS
+                lat_rounds++; lat_segs += (uint32_t)nseg; lat_k = k; lat_S = S;
+#endif
                 const bool active = lane < nseg;
-                const uint32_t entry = (lane == 0) ? b : x_prev;
-                const uint32_t cnt = active ? ((lane == 0) ? cx : cy_prev) : 0u;
+                const bool mine1 = (by1 >> lane) & 1u;
+                const uint32_t entry = (lane == 0) ? b : (mine1 ? x1p1 : x2p2);
+                const uint32_t cnt = active ? ((lane == 0) ? cs[0] : (mine1 ? c2p1 : c3p2)) : 0u;
                 const uint32_t incl = wave_incl_scan_u32(cnt);
                 const uint32_t first_idx = incl - cnt;
                 // phase B: values
                 uint32_t pe = entry;
                 const uint32_t seg_end = b + ((uint32_t)lane + 1u) * S;
                 bool bad_lane = false;
-                if (!(FA_LAT_X & 4) && active && first_idx < todo) {
+                {
+                    const bool mine = !(FA_LAT_X & 4) && active && first_idx < todo;
                     uint32_t j = first_idx;
-                    while (pe < seg_end && j < todo) {
-                        uint32_t q = 0, A;
-                        for (;;) {
-                            A = lat_win(img, pe + q);
-                            if (A != 0 || pe + q >= lim || q > kLatUnaryMax) break;
-                            q += 32;
+                    for (;;) {
+                        const bool go = mine && !bad_lane && pe < seg_end && j < todo;
+                        if (__builtin_amdgcn_ballot_w64(go) == 0) break;
+                        const uint32_t pin = (go && pe < lim) ? pe : 0u;  // (a true code starts inside the frame)
+                        uint32_t A = lat_win_in(img, pin);
+                        uint32_t z = (uint32_t)__clz((int)A);
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(go && A == 0) != 0, 0)) {  // 32 zeros or more somewhere: the general reader
+                            if (go) {
+                                uint32_t q = 0;
+                                for (;;) {
+                                    A = lat_win(img, pe + q);
+                                    if (A != 0 || pe + q >= lim || q > kLatUnaryMax) break;
+                                    q += 32;
+                                }
+                                if (A == 0) bad_lane = true;
+                                z = q + (uint32_t)__clz((int)A);
+                            }
                         }
-                        if (A == 0) { bad_lane = true; break; }
-                        const uint32_t z = q + (uint32_t)__clz((int)A);
                         const uint32_t lowpos = pe + z + 1u;
-                        const uint32_t low = k ? (lat_win(img, lowpos) >> (32 - k)) : 0u;
+                        const uint32_t low = k ? (lat_win(img, (go && !bad_lane) ? lowpos : 0u) >> (32 - k)) : 0u;
                         const uint32_t uu = (z << k) | low;
-                        res[idx0 + j] = (int32_t)(uu >> 1) ^ -(int32_t)(uu & 1);
-                        pe = lowpos + k;
-                        ++j;
+                        const bool put = go && !bad_lane;
+                        // (lanes that are done store into the last pad word, which nobody reads)
+                        res[put ? idx0 + j : (uint32_t)(kLatMaxBlock + kLatResPad - 1)] = (int32_t)(uu >> 1) ^ -(int32_t)(uu & 1);
+                        pe = put ? lowpos + k : pe;
+                        j += put ? 1u : 0u;
                     }
                 }
                 if (__any(bad_lane)) { give_up(16); return; }
@@ -421,6 +517,7 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
             if (last_partition_needed) break;
         }
         __syncthreads();
+        FA_LAT_STAMP(3);
         // ---- predictor ----
         if ((FA_LAT_X & 1) != 0) {
         } else if (is_lpc) {
@@ -455,6 +552,7 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
     }
     __syncthreads();
 
+    FA_LAT_STAMP(4);
     // ---- store [lo, hi) ----
     const int64_t row0 = out_off + (fstart - sl_first);
     auto sample = [&](int i) __attribute__((always_inline)) -> int32_t { return (int32_t)((uint32_t)res[i] << wasted); };
@@ -465,6 +563,13 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
     } else {
         for (int i = lo + lane; i < hi; i += 64) a.out_i32[row0 + i] = sample(i);
     }
+#if FA_LAT_STAMPS
+    FA_LAT_STAMP(5);
+    if (task == 0 && lane == 0)
+        printf("K7L stamps (us): image %.2f headers %.2f parse %.2f predictor %.2f store %.2f | partitions %u rounds %u segments resolved %u codes %u last k %u last S %u bits\n", (lat_t[1] - lat_t[0]) * 0.01,
+               (lat_t[2] - lat_t[1]) * 0.01, (lat_t[3] - lat_t[2]) * 0.01, (lat_t[4] - lat_t[3]) * 0.01, (lat_t[5] - lat_t[4]) * 0.01,
+               lat_parts, lat_rounds, lat_segs, lat_codes, lat_k, lat_S);
+#endif
 }
 
 }  // namespace fa
