@@ -106,11 +106,12 @@ constexpr int kLatResPad = 48;  // the predictor loops work in whole blocks of 1
 // ~6 cycles, profiles/r01k_valu_rates.txt: 116 us of an order-8 frame's 182 were the predictor with order + 4
 // instructions per sample on every lane alike.)
 template <int K>
-__device__ __forceinline__ double lat_floor_bcast(double a) {
+__device__ __forceinline__ void lat_lpc_step(double& acc, double c) {
     double x;
-    // (two wait states between the vector instruction that wrote `a` and a DPP read of it)
-    asm volatile("s_nop 1\n\tv_floor_f64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(x) : "v"(a), "n"(K));
-    return x;
+    // (two wait states between the vector instruction that wrote `acc` and a DPP read of it; floor and FMA sit in one
+    // statement so that the compiler does not pad the DPP's result with a wait state of its own)
+    asm volatile("s_nop 1\n\tv_floor_f64_dpp %0, %1 row_newbcast:%3 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64 %1, %0, %2"
+                 : "=&v"(x), "+v"(acc) : "v"(c), "n"(K));
 }
 
 __device__ __forceinline__ void lat_restore_lpc(int32_t* res, const double* coef16, int order, int hi) {
@@ -134,7 +135,7 @@ __device__ __forceinline__ void lat_restore_lpc(int32_t* res, const double* coef
             out = mine ? t : out;
             acc = mine ? rn : acc;
         };
-#define FA_LAT_STEP(K) { const double x = lat_floor_bcast<K>(acc); acc = __builtin_fma(x, cr[K], acc); }
+#define FA_LAT_STEP(K) lat_lpc_step<K>(acc, cr[K]);
         FA_LAT_STEP(0) FA_LAT_STEP(1) FA_LAT_STEP(2) FA_LAT_STEP(3)
         hand_over(g0);
         FA_LAT_STEP(4) FA_LAT_STEP(5) FA_LAT_STEP(6) FA_LAT_STEP(7)
@@ -412,21 +413,30 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
                 for (int w = 0; w < 3; ++w) {
                     const uint32_t limw = lim1 + (uint32_t)w * S;
                     uint32_t c = 0;
-                    for (;;) {
-                        ended = ended || q0 >= lim;  // (behind the frame: zeros, no code)
-                        const bool go = !ended && q0 < limw;
-                        if (__builtin_amdgcn_ballot_w64(go) == 0) break;
-                        const uint32_t A = lat_win_in(img, ended ? 0u : q0);
-                        uint32_t len = (uint32_t)__clz((int)A) + 1u + k;
-                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(go && A == 0) != 0, 0)) {  // 32 zeros or more somewhere: the general reader
-                            if (go) {
-                                len = lat_code_len(img, q0, k, lim);
+                    for (;;) {  // four codes per trip: the trip's bookkeeping is as long as a code's own work (1 / 2 / 4 per trip: 53 / 49 / 46 us)
+                        bool slow = false;
+                        auto step = [&]() __attribute__((always_inline)) -> bool {
+                            ended = ended || q0 >= lim;  // (behind the frame: zeros, no code)
+                            const bool go = !ended && q0 < limw;
+                            const uint32_t A = lat_win_in(img, ended ? 0u : q0);
+                            const bool adv = go && A != 0;
+                            slow = slow || (go && A == 0);  // 32 zeros or more: the general reader below
+                            q0 += adv ? (uint32_t)__clz((int)A) + 1u + k : 0u;
+                            c += adv ? 1u : 0u;
+                            return go;
+                        };
+                        const bool any_go = __builtin_amdgcn_ballot_w64(step()) != 0;
+                        if (!any_go) break;
+                        (void)step();
+                        (void)step();
+                        (void)step();
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(slow) != 0, 0)) {
+                            if (slow) {
+                                const uint32_t len = lat_code_len(img, q0, k, lim);
                                 if (len == 0) ended = true;
+                                else { q0 += len; c++; }
                             }
                         }
-                        const bool adv = go && !ended;
-                        q0 += adv ? len : 0u;
-                        c += adv ? 1u : 0u;
                     }
                     xs[w] = ended ? 0xffffffffu : q0;
                     cs[w] = c;
