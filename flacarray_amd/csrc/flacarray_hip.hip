@@ -353,9 +353,6 @@ int run_verify(const DecodeArgs& a, int* d_err, int* h_err, hipStream_t st, int 
     return FA_ERROR_NONE;
 }
 
-// K7L (one wavefront per frame) is used for launches of at most this many frames; above it the throughput decoder's
-// 64 frames per wave win (K7L holds ~34 KB of LDS per frame: ~1000 frames in flight, ~60-140 us each).
-// FLACARRAY_HIP_LATENCY=0 disables it, =1 forces it for every launch of up to 65535 frames (tests).
 constexpr size_t kPinBytes = 512u << 10;  // samples (larger results go by DMA: 1.6 MB took 307 us this way, 298 by copy); 64 bytes of status words follow
 bool pinned_landing(void** host, void** dev) {
     DeviceState* ds = dev_state();
@@ -376,11 +373,15 @@ bool pinned_landing(void** host, void** dev) {
     return ds->pin != nullptr;
 }
 
+// K7L (one wavefront per frame) is used for launches of at most 8192 frames; above it the throughput decoder's 64 frames
+// per wave win (K7L holds ~34 KB of LDS per frame: ~1000 frames in flight, 45-95 us each; measured crossover,
+// tools/lat_crossover.py: 4000 slices = ~6000 frames 0.79 ms against K7's 1.18, 8000 slices 1.45 against 0.93).
+// FLACARRAY_HIP_LATENCY=0 disables it, =1 forces it for every launch of up to 65535 frames (tests).
 bool latency_allowed(int64_t n_tasks) {
     const char* e = std::getenv("FLACARRAY_HIP_LATENCY");  // (read per call: the tests switch it)
     if (e && e[0] == '0') return false;
     if (e && e[0] == '1') return n_tasks <= 65535;
-    return n_tasks <= 2048;
+    return n_tasks <= 8192;
 }
 
 // A decode index: what K6 derives from a store (stream metadata, the byte offset of every frame), kept in device memory
