@@ -1177,6 +1177,48 @@ def test_latency_decoder_matches_throughput_decoder(fa, oracle, monkeypatch):
                 ix.close()
 
 
+def test_small_reads_landing_in_pinned_host_memory(fa, oracle):
+    """A read of up to 512 KB that wants numpy output has its samples and the status word written by the latency decoder
+    straight into pinned host memory (csrc/flacarray_hip.hip, decode_device_impl).  Same samples as a device read; a
+    frame the latency decoder does not take (predictor order 20 in the hand-assembled vector g7) makes the call fall
+    back to the ordinary path with the same result; larger results go by copy."""
+    import os
+
+    import torch
+
+    v = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "flac_vectors.npz"))
+    s, st, n = v["g7_deep_samples"], v["g7_deep_stream"], int(v["g7_deep_size"])
+    blob = np.concatenate([st, np.zeros((-st.size) % 16, np.uint8), st])
+    second = st.size + (-st.size) % 16
+    dev = (torch.from_numpy(blob).cuda(), torch.tensor([0, second], dtype=torch.int64).cuda(), torch.full((2,), st.size, dtype=torch.int64).cuda())
+    ix = fa.DeviceDecodeIndex(*dev, n)
+    try:
+        rng = np.random.default_rng(4)
+        for _ in range(20):
+            k = int(rng.integers(1, 6))
+            ch = rng.integers(0, 2, k)
+            cnt = rng.integers(1, min(n, 3000), k)
+            first = np.array([rng.integers(0, n - c + 1) for c in cnt])
+            host, off = ix.decode_slices(ch, first, cnt, to_host=True)
+            flat, _ = ix.decode_slices(ch, first, cnt)
+            want = np.concatenate([s[f : f + c] for f, c in zip(first, cnt)])
+            assert isinstance(host, np.ndarray) and np.array_equal(host, want) and np.array_equal(flat.cpu().numpy(), want)
+    finally:
+        ix.close()
+    # own streams: small (pinned) and large (copied) host results
+    x = sinusoid_noise_i32(6, 100000, seed=77)
+    b2, st2, nb2 = oracle.encode_i32(x, 5)
+    ix = fa.DeviceDecodeIndex(torch.from_numpy(b2).cuda(), torch.from_numpy(st2).cuda(), torch.from_numpy(nb2).cuda(), 100000)
+    try:
+        for cnt in (1, 4095, 4097, 70000):  # 70000 x 6 x 4 bytes > 512 KB
+            ch = np.arange(6)
+            first = np.full(6, 12345)
+            host, off = ix.decode_slices(ch, first, np.full(6, cnt), to_host=True)
+            assert np.array_equal(host.reshape(6, cnt), x[:, 12345 : 12345 + cnt])
+    finally:
+        ix.close()
+
+
 def test_single_pass_capacity_smaller_than_worst_case(fa, oracle):
     """The single-pass encoder writes into a caller-provided buffer.  Sized below the worst case it must either hold
     the blob (same bytes) or refuse cleanly with ERROR_ALLOC -- no frame, tail frame or stream header may be written
