@@ -296,10 +296,11 @@ def bench_small_reads(fa, comp, st, nb, n_ch, n_samp, x):
         for i in range(5):
             out, _ = ix.decode_slices(ch[i : i + 1], first[i : i + 1], cnt[i : i + 1], to_host=True)
             assert np.array_equal(out, x[ch[i], first[i] : first[i] + cnt[i]].cpu().numpy())
-        t0 = time.perf_counter()
-        for i in range(200):
-            ix.decode_slices(ch[i : i + 1], first[i : i + 1], cnt[i : i + 1], to_host=True)
-        single = (time.perf_counter() - t0) / 200
+        for _ in range(2):  # second of two passes (the first one's results open the pinned result pool's size classes: ~10 ms each, once)
+            t0 = time.perf_counter()
+            for i in range(200):
+                ix.decode_slices(ch[i : i + 1], first[i : i + 1], cnt[i : i + 1], to_host=True)
+            single = (time.perf_counter() - t0) / 200
         ix.decode_slices(ch[:100], first[:100], cnt[:100], to_host=True)
         t0 = time.perf_counter()
         for r in range(20):

@@ -46,6 +46,8 @@ SYMBOLS = [
     "fa_set_decode_verify",
     "fa_encode_f32_host",
     "fa_decode_indexed_host",
+    "fa_pinned_alloc",
+    "fa_pinned_free",
     "fa_profile_enable",
     "fa_profile_last",
     "fa_profile_read",
@@ -126,6 +128,10 @@ def lib():
     L.fa_encode_f32_host.restype = cint
     L.fa_decode_indexed_host.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, cint]
     L.fa_decode_indexed_host.restype = cint
+    L.fa_pinned_alloc.argtypes = [i64]
+    L.fa_pinned_alloc.restype = vp
+    L.fa_pinned_free.argtypes = [vp]
+    L.fa_pinned_free.restype = None
     L.fa_set_decode_verify.argtypes = [cint]
     L.fa_set_decode_verify.restype = cint
     L.fa_profile_enable.argtypes = [cint]

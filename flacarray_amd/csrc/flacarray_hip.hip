@@ -587,11 +587,20 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
         // and the launch is repeated by K7 below.
         const bool verifying = (verify < 0 ? g_verify.load() : verify != 0);
         void *pin_h = nullptr, *pin_d = nullptr;
-        if (h_copy && h_copy_bytes && h_copy_bytes <= kPinBytes && !verifying && pinned_landing(&pin_h, &pin_d)) {
+        // (the caller's own buffer, if it is pinned and device-visible -- fa_pinned_alloc, any hipHostMalloc --, takes
+        // the samples directly whatever their size; otherwise the library's landing buffer, for results up to 512 KB)
+        void* direct = nullptr;
+        if (h_copy && h_copy_bytes && !verifying) {
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, h_copy) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) direct = at.devicePointer;
+            else (void)hipGetLastError();
+        }
+        if (h_copy && h_copy_bytes && (direct || h_copy_bytes <= kPinBytes) && !verifying && pinned_landing(&pin_h, &pin_d)) {
             // a small read that wants its samples on the host: the kernel stores them and its status word into pinned
             // host memory; what is left for the host is one synchronisation and a memcpy of a few KB
             DecodeArgs ap = a;
-            if (f32) ap.out_f32 = reinterpret_cast<float*>(pin_d); else ap.out_i32 = reinterpret_cast<int32_t*>(pin_d);
+            void* const land = direct ? direct : pin_d;
+            if (f32) ap.out_f32 = reinterpret_cast<float*>(land); else ap.out_i32 = reinterpret_cast<int32_t*>(land);
             volatile int* status = reinterpret_cast<volatile int*>(reinterpret_cast<char*>(pin_h) + kPinBytes);
             status[0] = 0;
             int* d_status = reinterpret_cast<int*>(reinterpret_cast<char*>(pin_d) + kPinBytes);
@@ -603,7 +612,7 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
             FA_HIP_TRY(hipStreamSynchronize(st));
             FA_HIP_TRY(hipGetLastError());
             if (status[0] == 0) {
-                std::memcpy(h_copy, pin_h, h_copy_bytes);
+                if (!direct) std::memcpy(h_copy, pin_h, h_copy_bytes);
                 if (h_copied) *h_copied = true;
                 return FA_ERROR_NONE;
             }
@@ -1248,6 +1257,20 @@ int fa_decode_indexed(void* index, int64_t first_sample, int64_t last_sample, in
                               out_offset, nullptr, nullptr, nullptr, nullptr, st, 2, reinterpret_cast<int64_t*>(d_out_int),
                               reinterpret_cast<double*>(d_out_float), reinterpret_cast<const double*>(d_offsets),
                               reinterpret_cast<const double*>(d_gains), ix, false, verify);
+}
+
+void* fa_pinned_alloc(int64_t bytes) {
+    if (bytes <= 0 || fa_device_count() <= 0) return nullptr;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void fa_pinned_free(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int fa_decode_indexed_host(void* index, int64_t n_slices, const int64_t* slice_stream, const int64_t* slice_first,

@@ -11,7 +11,9 @@ The int64 / float64 twins (`wrap_encode_i64[_threaded]` :407/:468, `wrap_decode_
 same kernels.
 """
 import ctypes
+import os
 import sys
+import threading
 import weakref
 
 import numpy as np
@@ -38,6 +40,85 @@ def _adopt_malloc(addr, n):
     arr = np.frombuffer(buf, dtype=np.uint8)
     weakref.finalize(buf, _lib.libc_free, addr)
     return arr
+
+
+class _PinnedPool:
+    """Pinned, device-visible host blocks behind the numpy arrays the small-read paths return.
+
+    A read whose samples are wanted on the host is fastest when the decoder writes them where they are going: into
+    pinned memory (fa_decode_indexed_host, include/flacarray_hip.h).  A fresh numpy array is neither pinned nor present
+    (its pages appear on first touch, ~19 GB/s on the benchmark host: 75 of the 250 us of a 100-slice read), so results
+    from 64 KB to 64 MB come from this pool instead: power-of-two blocks, handed back when the last view of the
+    array dies and kept for the next read (at most FLACARRAY_HIP_PINNED_POOL_MB, default 256, sit idle; at most
+    FLACARRAY_HIP_PINNED_MAX_MB, default 1024, are out at any time -- beyond that, and whenever pinned memory is not to be
+    had, the caller gets an ordinary array).  FLACARRAY_HIP_PINNED_POOL_MB=0 switches the pool off."""
+
+    _MIN, _MAX = 65536, 64 << 20
+
+    def __init__(self):
+        self._free = {}
+        self._idle = 0
+        self._out = 0
+        self._lock = threading.Lock()
+        self._idle_limit = int(os.environ.get("FLACARRAY_HIP_PINNED_POOL_MB", "256")) << 20
+        self._out_limit = int(os.environ.get("FLACARRAY_HIP_PINNED_MAX_MB", "1024")) << 20
+
+    def _take(self, nbytes):
+        cap = max(self._MIN, 1 << max(nbytes - 1, 0).bit_length())
+        if self._idle_limit <= 0 or cap > self._MAX:
+            return None
+        with self._lock:
+            if self._out + cap > self._out_limit:
+                return None
+            self._out += cap
+            blocks = self._free.get(cap)
+            if blocks:
+                self._idle -= cap
+                return blocks.pop(), cap
+        addr = _lib.lib().fa_pinned_alloc(cap)
+        if not addr:
+            with self._lock:
+                self._out -= cap
+            return None
+        return addr, cap
+
+    def _give(self, addr, cap):
+        if sys is None or sys.is_finalizing():
+            return
+        with self._lock:
+            self._out -= cap
+            if self._idle + cap <= self._idle_limit:
+                self._free.setdefault(cap, []).append(addr)
+                self._idle += cap
+                return
+        _lib.lib().fa_pinned_free(addr)
+
+    def empty(self, n, dtype):
+        """1-D array of n elements on a pinned block, or None."""
+        dtype = np.dtype(dtype)
+        nbytes = int(n) * dtype.itemsize
+        if nbytes <= 0:
+            return None
+        got = self._take(nbytes)
+        if got is None:
+            return None
+        addr, cap = got
+        buf = (ctypes.c_uint8 * nbytes).from_address(addr)
+        fin = weakref.finalize(buf, self._give, addr, cap)
+        fin.atexit = False  # (at interpreter exit the block goes with the process)
+        return np.frombuffer(buf, dtype=dtype)
+
+    def drain(self):
+        """Free the idle blocks (tests; fa_release_scratch callers)."""
+        with self._lock:
+            blocks = [a for lst in self._free.values() for a in lst]
+            self._free.clear()
+            self._idle = 0
+        for a in blocks:
+            _lib.lib().fa_pinned_free(a)
+
+
+_pinned_pool = _PinnedPool()
 
 
 def wrap_float32_to_int32(flatdata, n_stream, stream_size, quanta, _f64=False):
@@ -680,7 +761,12 @@ class DeviceDecodeIndex:
             offsets = offsets.reshape(-1).to(device=self.device, dtype=ft).contiguous()
             gains = gains.reshape(-1).to(device=self.device, dtype=ft).contiguous()
         if to_host:
-            host = np.empty(out.numel(), dtype=np.dtype(str(dt).replace("torch.", "")))
+            ndt = np.dtype(str(dt).replace("torch.", ""))
+            # (64 KB and more: a pinned block the decoder writes straight into; below that the library's own landing
+            # buffer and a memcpy are cheaper than the pool's bookkeeping: 122 against 129 us per single read)
+            host = _pinned_pool.empty(out.numel(), ndt) if out.numel() * ndt.itemsize >= 65536 else None
+            if host is None:
+                host = np.empty(out.numel(), dtype=ndt)
             with torch.cuda.device(self.device):
                 errcode = self._L.fa_decode_indexed_host(
                     self._h, n, ctypes.c_void_p(slice_stream.ctypes.data), ctypes.c_void_p(slice_first.ctypes.data),

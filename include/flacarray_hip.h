@@ -181,12 +181,21 @@ int fa_decode_indexed(void* index, int64_t first_sample, int64_t last_sample, in
                       const int64_t* slice_first, const int64_t* slice_count, const int64_t* out_offset, void* d_out_int,
                       void* d_out_float, const void* d_offsets, const void* d_gains, void* stream, int verify);
 
-/* fa_decode_indexed for scattered slices whose samples are wanted on the HOST: decodes into the caller's device
- * buffer (d_out_int / d_out_float as above) and copies its first out_bytes bytes to h_out inside the same call -- for a
- * small read the samples travel with the status words and the call synchronises once. */
+/* fa_decode_indexed for scattered slices whose samples are wanted on the HOST: the first out_bytes bytes of the result
+ * are in h_out when the call returns.  For launches the latency decoder serves (mono, up to 8192 frames) the kernel
+ * writes them straight into host memory -- into h_out itself when that is pinned and device-visible (fa_pinned_alloc
+ * below, or any hipHostMalloc), else into the library's own pinned landing buffer for results of up to 512 KB, copied
+ * from there -- and the call synchronises once; otherwise the result is decoded into the caller's device buffer
+ * (d_out_int / d_out_float as above, always required) and copied.  What the reference does for one small read:
+ * seek_absolute + process_single into the caller's array, decompress.c:281-298. */
 int fa_decode_indexed_host(void* index, int64_t n_slices, const int64_t* slice_stream, const int64_t* slice_first,
                            const int64_t* slice_count, const int64_t* out_offset, void* d_out_int, void* d_out_float,
                            const void* d_offsets, const void* d_gains, void* h_out, int64_t out_bytes, void* stream, int verify);
+
+/* Pinned, device-visible host memory for results (hipHostMalloc / hipHostFree behind a C signature); NULL on failure.
+ * flacarray_amd keeps a small pool of such blocks behind the numpy arrays its read paths return. */
+void* fa_pinned_alloc(int64_t bytes);
+void fa_pinned_free(void* p);
 
 /* Integrity check of the decoder.  Every device decode entry point takes `verify`: 1 = re-compute the CRC-16 of each
  * frame the call read and report a mismatch as FA_ERROR_DECODE_PROCESS -- what libFLAC reports through the error

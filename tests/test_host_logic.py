@@ -15,7 +15,7 @@ from flacarray_amd import _lib, libflacarray
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "flacarray_hip.h")).read()
-    declared = set(re.findall(r"^\s*(?:int64_t|int|void|const char\*)\s+(\w+)\(", header, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int64_t|int|void\*?|const char\*)\s+(\w+)\(", header, flags=re.M))
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     L = ctypes.CDLL(_lib.LIB_PATH)
     for sym in declared:

@@ -23,10 +23,11 @@ def main():
     xs = x.cpu().numpy()
     for i in range(5):  # warm up + check
         assert np.array_equal(store[int(ch[i]), int(first[i]) : int(first[i] + cnt[i])], xs[ch[i], first[i] : first[i] + cnt[i]])
-    t0 = time.perf_counter()
-    for i in range(1000):
-        store[int(ch[i]), int(first[i]) : int(first[i] + cnt[i])]
-    dt = (time.perf_counter() - t0) / 1000
+    for _ in range(2):  # second of two passes: the first opens the size classes of the pinned result pool (~10 ms each, once)
+        t0 = time.perf_counter()
+        for i in range(1000):
+            store[int(ch[i]), int(first[i]) : int(first[i] + cnt[i])]
+        dt = (time.perf_counter() - t0) / 1000
     print(f"__getitem__ one slice per call: {dt*1e6:8.1f} us/call  {1/dt:9.0f} reads/s")
     for nb in (1, 10, 100, 1000):
         reps = max(2000 // nb, 3)
