@@ -295,3 +295,47 @@ def test_zarr_v1_layout_roundtrip(oracle):
     ls, gs, comp, nch, s2, n2, o2, g2, dist, idx = Z.read_compressed(g)
     assert ls == (4, 3000) and o2 is None and g2 is None
     assert np.array_equal(oracle.decode_i32(comp, s2, n2, 3000), x)
+
+
+def test_pinned_result_pool_recycles_blocks(monkeypatch):
+    """The pool behind host results of small reads (libflacarray._PinnedPool): power-of-two blocks, handed back when the
+    last view of the array dies, re-used by the next request of the class, bounded idle and outstanding totals.  The
+    allocator is replaced by malloc here (pinned memory needs a GPU)."""
+    import gc
+
+    libc = ctypes.CDLL(None)
+    libc.malloc.restype = ctypes.c_void_p
+    libc.malloc.argtypes = [ctypes.c_size_t]
+    libc.free.argtypes = [ctypes.c_void_p]
+    calls = {"alloc": 0, "free": 0}
+
+    class FakeLib:
+        def fa_pinned_alloc(self, cap):
+            calls["alloc"] += 1
+            return libc.malloc(cap)
+
+        def fa_pinned_free(self, addr):
+            calls["free"] += 1
+            libc.free(addr)
+
+    monkeypatch.setattr(_lib, "lib", lambda: FakeLib())
+    monkeypatch.setenv("FLACARRAY_HIP_PINNED_POOL_MB", "1")
+    monkeypatch.setenv("FLACARRAY_HIP_PINNED_MAX_MB", "2")
+    pool = libflacarray._PinnedPool()
+    for i in range(50):  # one class, one live array at a time: one allocation in all
+        a = pool.empty(20000 + i, np.int32)
+        a[:] = i
+        view = a.reshape(1, -1)[:, 5:]
+        del a
+        assert int(view[0, 0]) == i  # (the block lives as long as any view of it)
+        del view
+    gc.collect()
+    assert calls == {"alloc": 1, "free": 0} and pool._out == 0 and pool._idle == 131072
+    held = [pool.empty(100000, np.float32) for _ in range(4)]  # 512 KB blocks: four fit the 2 MB that may be out
+    assert all(h is not None for h in held) and pool.empty(100000, np.float32) is None
+    del held
+    gc.collect()
+    assert pool._out == 0 and pool._idle <= (1 << 20) and calls["free"] >= 2  # (idle blocks beyond 1 MB are freed)
+    assert pool.empty(0, np.int32) is None and pool.empty((64 << 20) // 4 + 1, np.int32) is None
+    pool.drain()
+    assert pool._idle == 0
