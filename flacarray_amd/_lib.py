@@ -190,6 +190,16 @@ def libc_free(addr):
     _libc.free(addr)
 
 
+def libc_madvise(addr, length, advice):
+    """madvise(2) on a range of this process' memory; returns its result (0 = accepted)."""
+    global _libc
+    if _libc is None:
+        libc_free(None)  # (loads libc; free(NULL) does nothing)
+    _libc.madvise.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    _libc.madvise.restype = ctypes.c_int
+    return _libc.madvise(ctypes.c_void_p(addr), length, advice)
+
+
 def require_device():
     """Raise unless a HIP device is visible (the product path never falls back to the CPU)."""
     if lib().fa_device_count() <= 0:
