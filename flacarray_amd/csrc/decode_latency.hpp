@@ -149,10 +149,21 @@ __device__ __forceinline__ void lat_restore_lpc(int32_t* res, const double* coef
     }
 }
 
-template <bool F32>
-__global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInline inl, int* fallback) {
+// outputs of the two-channel variant (int64 / float64 arrays: low and high word of a sample are the two channels,
+// utils.c:96-123; the restore is utils.c:329-348)
+struct LatWide {
+    int64_t* out_i64;
+    double* out_f64;
+    const double* offsets;
+    const double* gains;
+};
+
+// NCH == 2: frames with two INDEPENDENT channels (what the int64 encoder writes for all but small-valued frames); the
+// side assignments, whose side channel has 33 bits, stay with K7.  F32 then means "float64 output".
+template <bool F32, int NCH>
+__global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInline inl, LatWide wd, int* fallback) {
     __shared__ __attribute__((aligned(16))) uint32_t img[kLatImgWords + kLatPadWords];
-    __shared__ __attribute__((aligned(16))) int32_t res[kLatMaxBlock + kLatResPad];
+    __shared__ __attribute__((aligned(16))) int32_t res_all[NCH][kLatMaxBlock + kLatResPad];
     __shared__ double coef_s[16];  // pre-scaled coefficients, zero from the order on
     const int lane = threadIdx.x;
     const int64_t task = blockIdx.x;
@@ -186,7 +197,7 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
     const StreamMeta m = a.meta[s];
     const int64_t at = a.ftab[s * a.nf + f];
     const int64_t nxt = (f + 1 < a.nf) ? a.ftab[s * a.nf + f + 1] : m.end_abs;
-    if (m.first_frame < 0 || at < 0 || nxt <= at + 6 || nxt > a.blob_bytes || a.B > kLatMaxBlock || m.channels != 1) { give_up(1); return; }
+    if (m.first_frame < 0 || at < 0 || nxt <= at + 6 || nxt > a.blob_bytes || a.B > kLatMaxBlock || m.channels != NCH) { give_up(1); return; }
     const int64_t base = at & ~(int64_t)15;
     const uint32_t skip = (uint32_t)(at - base);
     const uint32_t nbytes = skip + (uint32_t)(nxt - at);
@@ -249,7 +260,7 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
         if ((w >> 16) != 0xFFF8) bad = true;
         const uint32_t b2 = (w >> 8) & 0xff, b3 = w & 0xff;
         const int bsc = (int)(b2 >> 4), src = (int)(b2 & 15), ch = (int)(b3 >> 4), ssc = (int)((b3 >> 1) & 7);
-        if (ch != 0 || (b3 & 1)) bad = true;
+        if (ch != NCH - 1 || (b3 & 1)) bad = true;  // (one channel, or two independent ones)
         const uint32_t u0 = get(8);
         c8 = crc8_byte(c8, (uint8_t)u0);
         int extra = 0;
@@ -293,6 +304,12 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
     const int lo = (int)l0, hi = (int)(h0 > l0 ? h0 : l0);  // samples [lo, hi) of this frame are wanted
     if (hi <= lo) return;
 
+    int wasted_of[NCH];
+#pragma unroll 1
+    for (int chn = 0; chn < NCH; ++chn) {
+    int32_t* const res = res_all[chn];
+    // (the first of two channels is parsed to its end whatever the read wants: the second begins where it stops)
+    const int hi_parse = (NCH == 2 && chn == 0) ? bs : hi;
     // ---- subframe ----
     const uint32_t sf = get(8);
     const int tc = (int)((sf >> 1) & 0x3f);
@@ -318,6 +335,7 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
             const uint32_t v = lat_win(img, pos + (uint32_t)i * (uint32_t)bps) >> (32 - bps);
             res[i] = (int32_t)(v << (32 - bps)) >> (32 - bps);
         }
+        pos += (uint32_t)bps * (uint32_t)bs;
     } else if ((tc >= 8 && tc <= 12) || tc >= 32) {
         if (tc >= 32) { order = (tc & 31) + 1; is_lpc = true; }
         else order = tc - 8;
@@ -349,7 +367,7 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
         // ---- residual: partitions in turn, the codes of a partition in parallel ----
         uint32_t idx0 = (uint32_t)order;           // sample index of the next residual
         uint32_t left_in_frame = (uint32_t)(bs - order);
-        for (int p = 0; p < (1 << po) && idx0 < (uint32_t)hi; ++p) {
+        for (int p = 0; p < (1 << po) && idx0 < (uint32_t)hi_parse; ++p) {
             uint32_t n = (uint32_t)(p == 0 ? ps - order : ps);
             const uint32_t k = get(plen);
             if (bad) { give_up(8); return; }
@@ -371,7 +389,7 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
             }
             // nothing behind the last wanted sample is decoded
             uint32_t want = n;
-            if (idx0 + want > (uint32_t)hi) want = (uint32_t)hi - idx0;
+            if (idx0 + want > (uint32_t)hi_parse) want = (uint32_t)hi_parse - idx0;
             const bool last_partition_needed = (want < n);
             uint32_t b = pos, todo = want;
 #if FA_LAT_STAMPS
@@ -560,13 +578,28 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
         give_up(4);
         return;
     }
+    wasted_of[chn] = wasted;
     __syncthreads();
+    }  // (channels)
 
     FA_LAT_STAMP(4);
     // ---- store [lo, hi) ----
     const int64_t row0 = out_off + (fstart - sl_first);
-    auto sample = [&](int i) __attribute__((always_inline)) -> int32_t { return (int32_t)((uint32_t)res[i] << wasted); };
-    if constexpr (F32) {
+    auto sample = [&](int i) __attribute__((always_inline)) -> int32_t { return (int32_t)((uint32_t)res_all[0][i] << wasted_of[0]); };
+    if constexpr (NCH == 2) {
+        // channel 0 is the low word, channel 1 the high word (utils.c:96-123)
+        auto wide = [&](int i) __attribute__((always_inline)) -> int64_t {
+            const uint32_t lw = (uint32_t)res_all[0][i] << wasted_of[0], hw = (uint32_t)res_all[NCH - 1][i] << wasted_of[NCH - 1];
+            return (int64_t)(((uint64_t)hw << 32) | lw);
+        };
+        if constexpr (F32) {
+            const double og = wd.offsets[s];
+            const double cf = 1.0 / wd.gains[s];  // utils.c:342
+            for (int i = lo + lane; i < hi; i += 64) wd.out_f64[row0 + i] = og + cf * (double)wide(i);  // utils.c:345 (as K8)
+        } else {
+            for (int i = lo + lane; i < hi; i += 64) wd.out_i64[row0 + i] = wide(i);
+        }
+    } else if constexpr (F32) {
         const float og = a.offsets[s];
         const float cf = (float)(1.0 / (double)a.gains[s]);  // utils.c:361
         for (int i = lo + lane; i < hi; i += 64) a.out_f32[row0 + i] = __fadd_rn(og, __fmul_rn(cf, (float)sample(i)));  // utils.c:364

@@ -528,7 +528,7 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
         }
         a.n_tasks = n_tasks;
         if (a.n_tasks == 0) return FA_ERROR_NONE;
-        if (n_tasks <= 8 && nch == 1 && latency_allowed(n_tasks)) {
+        if (n_tasks <= 8 && latency_allowed(n_tasks)) {
             // a handful of frames: the task table rides in the kernel arguments (no upload, no synchronisation)
             int64_t t = 0;
             for (int64_t i = 0; i < n_slices; ++i) {
@@ -581,7 +581,20 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
     if (a.B > kMaxBlock * 16) return FA_ERROR_DECODE_INIT;
     const unsigned nblk = (unsigned)((a.n_tasks + 63) / 64);
     const bool f32 = (d_out_f32 != nullptr);
-    if (nch == 1 && a.B <= kLatMaxBlock && latency_allowed(a.n_tasks)) {
+    const bool f64 = (d_out_f64 != nullptr);
+    if (a.B <= kLatMaxBlock && latency_allowed(a.n_tasks)) {
+        LatWide wd;
+        wd.out_i64 = d_out_i64; wd.out_f64 = d_out_f64; wd.offsets = d_offsets64; wd.gains = d_gains64;
+        auto launch_latency = [&](const DecodeArgs& aa, int* flag) {
+            const dim3 grid((unsigned)a.n_tasks), block(64);
+            if (nch == 2) {
+                if (f64) hipLaunchKernelGGL((decode_latency_kernel<true, 2>), grid, block, 0, st, aa, inl, wd, flag);
+                else hipLaunchKernelGGL((decode_latency_kernel<false, 2>), grid, block, 0, st, aa, inl, wd, flag);
+            } else {
+                if (f32) hipLaunchKernelGGL((decode_latency_kernel<true, 1>), grid, block, 0, st, aa, inl, wd, flag);
+                else hipLaunchKernelGGL((decode_latency_kernel<false, 1>), grid, block, 0, st, aa, inl, wd, flag);
+            }
+        };
         // K7L: one wavefront per frame (decode_latency.hpp).  A launch with fewer frames than the chip has lanes is
         // latency bound in K7 (one lane per frame: ~1 ms whatever the count); frames K7L does not take set the flag
         // and the launch is repeated by K7 below.
@@ -590,12 +603,12 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
         // (the caller's own buffer, if it is pinned and device-visible -- fa_pinned_alloc, any hipHostMalloc --, takes
         // the samples directly whatever their size; otherwise the library's landing buffer, for results up to 512 KB)
         void* direct = nullptr;
-        if (h_copy && h_copy_bytes && !verifying) {
+        if (nch == 1 && h_copy && h_copy_bytes && !verifying) {
             hipPointerAttribute_t at;
             if (hipPointerGetAttributes(&at, h_copy) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) direct = at.devicePointer;
             else (void)hipGetLastError();
         }
-        if (h_copy && h_copy_bytes && (direct || h_copy_bytes <= kPinBytes) && !verifying && pinned_landing(&pin_h, &pin_d)) {
+        if (nch == 1 && h_copy && h_copy_bytes && (direct || h_copy_bytes <= kPinBytes) && !verifying && pinned_landing(&pin_h, &pin_d)) {
             // a small read that wants its samples on the host: the kernel stores them and its status word into pinned
             // host memory; what is left for the host is one synchronisation and a memcpy of a few KB
             DecodeArgs ap = a;
@@ -605,8 +618,7 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
             status[0] = 0;
             int* d_status = reinterpret_cast<int*>(reinterpret_cast<char*>(pin_d) + kPinBytes);
             prof_begin(2, st);
-            if (f32) hipLaunchKernelGGL((decode_latency_kernel<true>), dim3((unsigned)a.n_tasks), dim3(64), 0, st, ap, inl, d_status);
-            else hipLaunchKernelGGL((decode_latency_kernel<false>), dim3((unsigned)a.n_tasks), dim3(64), 0, st, ap, inl, d_status);
+            launch_latency(ap, d_status);
             prof_end(2, st);
             prof_end(4, st);
             FA_HIP_TRY(hipStreamSynchronize(st));
@@ -619,8 +631,7 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
             // (a frame the latency decoder does not take: the whole launch again, the ordinary way)
         }
         prof_begin(2, st);
-        if (f32) hipLaunchKernelGGL((decode_latency_kernel<true>), dim3((unsigned)a.n_tasks), dim3(64), 0, st, a, inl, d_err + 4);
-        else hipLaunchKernelGGL((decode_latency_kernel<false>), dim3((unsigned)a.n_tasks), dim3(64), 0, st, a, inl, d_err + 4);
+        launch_latency(a, d_err + 4);
         prof_end(2, st);
         prof_end(4, st);
         int h8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
