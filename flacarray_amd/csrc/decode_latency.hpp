@@ -9,18 +9,18 @@
 //   * headers, warm-up samples and predictor description are read by all lanes alike (uniform control flow);
 //   * the Rice codes of a partition are located in parallel: the partition's bit range is cut into 64 segments, every
 //     lane parses code LENGTHS from its segment's first bit -- usually the middle of a code -- through its own segment
-//     and the next one.  Two parses that ever stand on the same bit stay together, so lane l's parse is the true one
-//     from the point where it meets it; whether it met it before its segment ended is checked exactly: the true parse
-//     enters segment l+1 where lane l (if itself verified) left segment l, and leaves it where lane l's continued parse
-//     says -- lane l+1 is verified iff it left its own segment at that same bit.  Lane 0 starts on a code boundary and
-//     is always right; the leading run of verified lanes gives entry bit and code count of their segments, a prefix sum
-//     of the counts gives every code its sample index, and a second pass decodes the values.  Segments whose lane did
-//     not verify are simply taken up by the next round (which starts where the last verified segment ended);
-//   * the predictor runs on all lanes alike (the recurrence is serial; FIXED predictors in wrapping 32-bit integers,
-//     LPC in exact doubles as in K7), only as far as the last sample the read asks for;
+//     and the two after it.  Two parses that ever stand on the same bit stay together, and lane 0, which starts on a
+//     code boundary, is the true one: lane l's parse is known to be true from the entry of segment l + 1 on if it
+//     left its own segment where the true parse of lane l - 1 or l - 2 did.  A segment whose entry is reached by a true
+//     parse has a known entry bit and code count; the leading run of such segments gets sample indices from a prefix
+//     sum of the counts, a second pass decodes the values, and what is left (rarely anything) is taken up by the next
+//     round, which starts where the last resolved segment ended;
+//   * the predictor: FIXED on all lanes alike in wrapping 32-bit integers; LPC in exact doubles as in K7, in transposed
+//     form with the taps spread over the 16 lanes of a row (lat_restore_lpc), only as far as the last sample the read
+//     asks for;
 //   * the requested range is stored with coalesced stores (optionally dequantised, utils.c:350-368).
 //
-// What this kernel does not take (two channels, blocks above 4096 samples, predictor orders above 12, frames that do
+// What this kernel does not take (side / mid stereo assignments, blocks above 4096 samples, predictor orders above 12, frames that do
 // not fit the image, anything that does not parse) raises a flag and the launch is repeated by K7, which also owns
 // all error reporting.  Results are bit-identical to K7's.
 #pragma once
