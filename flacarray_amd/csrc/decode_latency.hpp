@@ -304,7 +304,7 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
     const int lo = (int)l0, hi = (int)(h0 > l0 ? h0 : l0);  // samples [lo, hi) of this frame are wanted
     if (hi <= lo) return;
 
-    int wasted_of[NCH];
+    int wasted_lo = 0, wasted_hi = 0;  // wasted bits of channel 0 / the last channel
 #pragma unroll 1
     for (int chn = 0; chn < NCH; ++chn) {
     int32_t* const res = res_all[chn];
@@ -578,18 +578,19 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
         give_up(4);
         return;
     }
-    wasted_of[chn] = wasted;
+    if (chn == 0) wasted_lo = wasted;
+    if (chn == NCH - 1) wasted_hi = wasted;
     __syncthreads();
     }  // (channels)
 
     FA_LAT_STAMP(4);
     // ---- store [lo, hi) ----
     const int64_t row0 = out_off + (fstart - sl_first);
-    auto sample = [&](int i) __attribute__((always_inline)) -> int32_t { return (int32_t)((uint32_t)res_all[0][i] << wasted_of[0]); };
+    auto sample = [&](int i) __attribute__((always_inline)) -> int32_t { return (int32_t)((uint32_t)res_all[0][i] << wasted_lo); };
     if constexpr (NCH == 2) {
         // channel 0 is the low word, channel 1 the high word (utils.c:96-123)
         auto wide = [&](int i) __attribute__((always_inline)) -> int64_t {
-            const uint32_t lw = (uint32_t)res_all[0][i] << wasted_of[0], hw = (uint32_t)res_all[NCH - 1][i] << wasted_of[NCH - 1];
+            const uint32_t lw = (uint32_t)res_all[0][i] << wasted_lo, hw = (uint32_t)res_all[NCH - 1][i] << wasted_hi;
             return (int64_t)(((uint64_t)hw << 32) | lw);
         };
         if constexpr (F32) {
