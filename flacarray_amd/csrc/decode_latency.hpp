@@ -32,10 +32,10 @@ namespace fa {
 #define FA_LAT_X 0  // timing experiments only (wrong results): 1 = no predictor, 2 = one parse round only, 4 = no value pass
 #endif
 #ifndef FA_LAT_SEG_BASE
-#define FA_LAT_SEG_BASE 32  // shortest segment of the speculative parse: FA_LAT_SEG_BASE + FA_LAT_SEG_PER_K * k codes
+#define FA_LAT_SEG_BASE 4  // shortest segment of the speculative parse: FA_LAT_SEG_BASE + (k + 1)^2 / FA_LAT_SEG_DIV codes
 #endif
-#ifndef FA_LAT_SEG_PER_K
-#define FA_LAT_SEG_PER_K 1
+#ifndef FA_LAT_SEG_DIV
+#define FA_LAT_SEG_DIV 36
 #endif
 #ifndef FA_LAT_STAMPS
 #define FA_LAT_STAMPS 0  // diagnostic build: lane 0 of task 0 prints where its time went (100 MHz ticks), tools/lat_time.py
@@ -399,8 +399,9 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
                 // segment length: this partition's share of the frame's remaining bits, spread over 64 lanes; at least
                 // a few codes long so that a parse started in the middle of a code has room to fall in step
                 const uint32_t rem_bits = frame_end_bits > b ? frame_end_bits - b : 64u;
-                uint64_t est = (uint64_t)rem_bits * todo / (left_in_frame ? left_in_frame : 1u);
-                uint32_t S = (uint32_t)(est >> 6) + 1u;
+                // (a heuristic: single precision will do, and a 64-bit integer division is ~100 instructions per round)
+                const float bits_per_code = (float)rem_bits / (float)(left_in_frame ? left_in_frame : 1u);
+                uint32_t S = (uint32_t)(bits_per_code * (float)todo * (1.0f / 64.0f)) + 1u;
                 // A parse that starts inside a code falls in step with the true one when the two land on the same bit;
                 // their distance does a random walk whose steps are the differences of the unary parts: a few codes at
                 // k = 0, around a hundred at k = 16 (noise-like data).  With ONE segment of continuation per lane a lane
@@ -408,10 +409,16 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
                 // (32 + 4 k codes: 64 us for a FIXED-0 frame of the benchmark data, k = 16..17; 32 codes: 125 us, 32 + 14 k:
                 // 154 us, profiles/r03_reads.md).  With TWO segments of continuation (below) the neighbour's parse carries
                 // the truth across such a lane and the frame's own spread over the 64 lanes (64 codes each) resolves in
-                // one round: minimum 32 + k codes, 53 us (32 + 4 k with the third walk: 75 us).
-                constexpr uint32_t kSegBase = FA_LAT_SEG_BASE, kSegPerK = FA_LAT_SEG_PER_K;
-                const uint32_t avg_bits = rem_bits / (left_in_frame ? left_in_frame : 1u) + 1u;
-                const uint32_t smin = (kSegBase + kSegPerK * k) * avg_bits;
+                // one round: 53 us (32 + 4 k with the third walk: 75 us).
+                // How long that takes grows with the square of the code length (the walk has to cover the code's length
+                // in steps of a bit or two): ~50 codes at k = 16, a handful at k = 4 -- and a frame with many small
+                // partitions, which are parsed one after the other, needs its lanes busy in each of them: the shortest
+                // segment is FA_LAT_SEG_BASE + (k + 1)^2 / FA_LAT_SEG_DIV codes (tools/lat_sweep.py, frames of 32
+                // partitions at noise amplitudes 2^1 .. 2^20: 32 + k codes whatever k: 0.92 - 1.08 ms; 4 + (k+1)^2 / 6:
+                // 0.37 - 1.58; / 12: 0.37 - 0.93; / 24: 0.37 - 0.61; / 48: 0.36 - 0.52; 4 codes: 0.35 - 1.04).
+                constexpr uint32_t kSegBase = FA_LAT_SEG_BASE, kSegDiv = FA_LAT_SEG_DIV;
+                const uint32_t avg_bits = (uint32_t)bits_per_code + 1u;
+                const uint32_t smin = (kSegBase + (k + 1u) * (k + 1u) / kSegDiv) * avg_bits;
                 if (S < smin) S = smin;
                 const uint32_t lim = frame_end_bits + 64u;
                 // phase A: code lengths through the lane's own segment and the two after it.  (Both phases read the image
