@@ -418,7 +418,12 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
                 // 0.37 - 1.58; / 12: 0.37 - 0.93; / 24: 0.37 - 0.61; / 48: 0.36 - 0.52; 4 codes: 0.35 - 1.04).
                 constexpr uint32_t kSegBase = FA_LAT_SEG_BASE, kSegDiv = FA_LAT_SEG_DIV;
                 const uint32_t avg_bits = (uint32_t)bits_per_code + 1u;
-                const uint32_t smin = (kSegBase + (k + 1u) * (k + 1u) / kSegDiv) * avg_bits;
+                // ... for SMALL partitions (at most 512 codes).  A big partition -- the benchmark's frames are one
+                // partition of 4088 codes -- is best served by segments long enough to verify at once, 32 + k codes, also
+                // when only its beginning is wanted (segments doubling from round to round, an eighth of the run as the
+                // minimum, a cap at a third of what is left: all measured, all slower on one of the two kinds of frame).
+                const uint32_t cmin = (n <= 512u) ? kSegBase + (k + 1u) * (k + 1u) / kSegDiv : 32u + k;
+                const uint32_t smin = cmin * avg_bits;
                 if (S < smin) S = smin;
                 const uint32_t lim = frame_end_bits + 64u;
                 // phase A: code lengths through the lane's own segment and the two after it.  (Both phases read the image

@@ -23,7 +23,8 @@ def main():
     xs = x.cpu().numpy()
     for i in range(5):  # warm up + check
         assert np.array_equal(store[int(ch[i]), int(first[i]) : int(first[i] + cnt[i])], xs[ch[i], first[i] : first[i] + cnt[i]])
-    for _ in range(2):  # second of two passes: the first opens the size classes of the pinned result pool (~10 ms each, once)
+    for _ in range(3):  # third of three passes: the first opens the size classes of the pinned result pool (~10 ms each,
+        # once), and a process' first seconds run at lower clocks (the same loop measures 160 us early and 121 us late)
         t0 = time.perf_counter()
         for i in range(1000):
             store[int(ch[i]), int(first[i]) : int(first[i] + cnt[i])]
