@@ -485,7 +485,10 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
                 const uint64_t mC = __ballot(lane >= 1 && xs[1] == x3p1);  // joins lane l-1 at the entry of segment l+2
                 if (__builtin_amdgcn_readfirstlane((int)cs[0]) == 0) { give_up(16); return; }  // not one code where one must be: damaged (K7 reports it)
                 uint64_t t1 = 1, t2 = 1;
-                for (int l = 1; l < 64; ++l) {
+                // (only as many segments as the codes still wanted can fill -- lanes behind them parse what follows the
+                // partition and would keep this scalar loop going for nothing; an underestimate costs another round)
+                const int need = (int)fminf(64.0f, bits_per_code * (float)todo / (float)S + 3.0f);
+                for (int l = 1; l < need; ++l) {
                     const uint64_t p1 = (t2 >> (l - 1)) & 1u, p2 = (l >= 2) ? ((t2 >> (l - 2)) & 1u) : 0u;
                     if (!(p1 | p2)) break;  // no true parse in the two lanes before: nothing reaches further
                     const uint64_t b1 = ((p1 & (mA >> l)) | (p2 & (mB >> l))) & 1u;
