@@ -75,8 +75,8 @@ for k, c in I.items():
         "lds_per_wave": round(c.get("SQ_INSTS_LDS", 0.0) / waves, 1),
     }
 # issue side (separate PMC pass): share of a wave's life in which it issues vector instructions, times the waves that
-# share a SIMD (K3F: 3 by its 168 registers; K7: 9 workgroups of one wave per CU by its 17.4 KB of LDS = 2.25)
-WAVES_PER_SIMD = {"encode_fused_kernel": 3.0, "decode_frames_kernel": 2.25, "encode_frames_kernel": 2.0}
+# share a SIMD (K3F: 3 by its 168 registers; K7: 2 by its 228 registers -- the 16.9 KB of LDS per workgroup would allow 9 per CU)
+WAVES_PER_SIMD = {"encode_fused_kernel": 3.0, "decode_frames_kernel": 2.0, "encode_frames_kernel": 2.0}
 pu = glob.glob(os.path.join(src, f"{tag}_pmcU/**/*counter_collection.csv"), recursive=True)
 if pu:
     copy_own_kernels(pu[0], os.path.join(dst, f"{tag}_pmc_issue.csv"))
