@@ -608,8 +608,13 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
         void* direct = nullptr;
         if (nch == 1 && h_copy && h_copy_bytes && !verifying) {
             hipPointerAttribute_t at;
-            if (hipPointerGetAttributes(&at, h_copy) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) direct = at.devicePointer;
-            else (void)hipGetLastError();
+            // (up to 2 MB: beyond that the kernel's 256-byte stores over the link are slower than one DMA copy out of
+            // the device buffer; at 16 MB the two cost the same, 1.04 ms per 1000-slice read, a quarter of it the Python list of results)
+            if (hipPointerGetAttributes(&at, h_copy) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) {
+                if (h_copy_bytes <= (2u << 20)) direct = at.devicePointer;
+            } else {
+                (void)hipGetLastError();
+            }
         }
         if (nch == 1 && h_copy && h_copy_bytes && (direct || h_copy_bytes <= kPinBytes) && !verifying && pinned_landing(&pin_h, &pin_d)) {
             // a small read that wants its samples on the host: the kernel stores them and its status word into pinned
