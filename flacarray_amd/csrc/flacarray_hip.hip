@@ -373,15 +373,17 @@ bool pinned_landing(void** host, void** dev) {
     return ds->pin != nullptr;
 }
 
-// K7L (one wavefront per frame) is used for launches of at most 8192 frames; above it the throughput decoder's 64 frames
-// per wave win (K7L holds ~34 KB of LDS per frame: ~1000 frames in flight, 45-95 us each; measured crossover,
-// tools/lat_crossover.py: 4000 slices = ~6000 frames 0.79 ms against K7's 1.18, 8000 slices 1.45 against 0.93).
+// K7L (one wavefront per frame) is used for launches of at most 4096 frames; above it the throughput decoder's 64 frames
+// per wave win (K7L holds ~34 KB of LDS per frame: ~1000 frames in flight).  Measured on the benchmark data (one Rice
+// partition per frame, 45-95 us each; tools/lat_crossover.py): 4000 slices = ~6000 frames 0.79 ms against K7's 1.18,
+// 8000 slices 1.45 against 0.93 -- a crossover near 8000 frames; frames of 32 partitions cost K7L 0.35-0.5 ms each
+// (tools/lat_sweep.py) and cross over near 2000.  4096 limits what either kind of data can lose to ~0.5 ms.
 // FLACARRAY_HIP_LATENCY=0 disables it, =1 forces it for every launch of up to 65535 frames (tests).
 bool latency_allowed(int64_t n_tasks) {
     const char* e = std::getenv("FLACARRAY_HIP_LATENCY");  // (read per call: the tests switch it)
     if (e && e[0] == '0') return false;
     if (e && e[0] == '1') return n_tasks <= 65535;
-    return n_tasks <= 8192;
+    return n_tasks <= 4096;
 }
 
 // A decode index: what K6 derives from a store (stream metadata, the byte offset of every frame), kept in device memory

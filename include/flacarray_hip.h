@@ -182,7 +182,7 @@ int fa_decode_indexed(void* index, int64_t first_sample, int64_t last_sample, in
                       void* d_out_float, const void* d_offsets, const void* d_gains, void* stream, int verify);
 
 /* fa_decode_indexed for scattered slices whose samples are wanted on the HOST: the first out_bytes bytes of the result
- * are in h_out when the call returns.  For launches the latency decoder serves (mono, up to 8192 frames) the kernel
+ * are in h_out when the call returns.  For launches the latency decoder serves (up to 4096 frames) the kernel
  * writes them straight into host memory -- into h_out itself when that is pinned and device-visible (fa_pinned_alloc
  * below, or any hipHostMalloc), else into the library's own pinned landing buffer for results of up to 512 KB, copied
  * from there -- and the call synchronises once; otherwise the result is decoded into the caller's device buffer

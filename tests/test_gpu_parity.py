@@ -18,7 +18,7 @@ def fa():
 
 @pytest.fixture(autouse=True, params=["auto", "k7"])
 def decoder_dispatch(request, monkeypatch):
-    """Launches of up to 8192 frames go to the wave-per-frame decoder K7L, larger ones to K7 (lane per frame, the
+    """Launches of up to 4096 frames go to the wave-per-frame decoder K7L, larger ones to K7 (lane per frame, the
     headline kernel).  The cases of this file are small, so left alone they would all exercise K7L: every test runs
     twice, once with the library's own dispatch and once with K7L switched off (the variable is read per call)."""
     if request.param == "k7":
