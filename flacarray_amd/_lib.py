@@ -54,7 +54,10 @@ SYMBOLS = [
     "fa_release_scratch",
     "fa_device_count",
     "fa_version",
+    "fa_abi_version",
 ]
+
+ABI_VERSION = 2  # FA_ABI_VERSION of include/flacarray_hip.h this binding was written against
 
 # error bits (flacarray.h:20-40 + this library's additions)
 ERROR_DEVICE = 1 << 24
@@ -82,6 +85,13 @@ def lib():
     except ImportError:
         pass
     L = ctypes.CDLL(LIB_PATH)
+    try:
+        L.fa_abi_version.restype = ctypes.c_int
+        found = L.fa_abi_version()
+    except AttributeError:
+        found = None
+    if found != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI revision {found}, this binding needs {ABI_VERSION}: rebuild it (python -m flacarray_amd.build --force)")
     i64, u32, vp, cint = ctypes.c_int64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int
     pi64 = ctypes.POINTER(ctypes.c_int64)
     L.encode_i32.argtypes = [vp, i64, i64, u32, pi64, vp, ctypes.POINTER(vp)]

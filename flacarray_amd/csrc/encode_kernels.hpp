@@ -122,6 +122,17 @@ __device__ __forceinline__ unsigned long long fa_memtime() {
             atomicAdd(&a.stamps[16], 1ULL);                                              \
         }                                                                                \
     } while (0)
+#elif defined(FA_PHASE_MARKS)
+// ISA bookkeeping build (tools/isa_phases.py): every stamp becomes a comment in the assembly, fenced so that no
+// instruction moves across it; the tool counts VALU / SALU / LDS / memory instructions between the marks.
+#define FA_STAMP(k)                                   \
+    do {                                              \
+        __builtin_amdgcn_sched_barrier(0);            \
+        asm volatile("; FA_MARK " #k ::: "memory");   \
+        __builtin_amdgcn_sched_barrier(0);            \
+    } while (0)
+#define FA_STAMP_INIT FA_STAMP(init)
+#define FA_STAMP_FLUSH FA_STAMP(end)
 #else
 #define FA_STAMP(k) do { } while (0)
 #define FA_STAMP_INIT do { } while (0)

@@ -513,6 +513,7 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
     std::vector<int64_t> h_tasks;
     size_t h_tasks_bytes = 0;
     char* d_tasks = nullptr;
+    bool tasks_uploaded = false;
     a.blob = d_bytes; a.blob_bytes = n_bytes; a.meta = d_meta; a.ftab = d_ftab; a.nf = nf; a.B = B;
     a.stream_size = stream_size;
     a.out_i32 = d_out_i32; a.out_f32 = d_out_f32; a.offsets = d_offsets; a.gains = d_gains; a.err = d_err;
@@ -533,8 +534,10 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
         }
         a.n_tasks = n_tasks;
         if (a.n_tasks == 0) return FA_ERROR_NONE;
-        if (n_tasks <= 8 && latency_allowed(n_tasks)) {
-            // a handful of frames: the task table rides in the kernel arguments (no upload, no synchronisation)
+        if (n_tasks <= 8 && B <= kLatMaxBlock && latency_allowed(n_tasks)) {
+            // a handful of frames K7L will take: the task table rides in the kernel arguments (no upload, no
+            // synchronisation).  The conditions are those of the K7L branch below -- a stream with larger blocks goes
+            // straight to K7, which reads the table from memory.
             int64_t t = 0;
             for (int64_t i = 0; i < n_slices; ++i) {
                 const int64_t s = slice_stream[i], fst = slice_first[i], cnt = slice_count[i];
@@ -656,6 +659,7 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
         if (inl.n > 0 && (h8[4] != 0 || verifying)) {  // K7 and the CRC-16 check read the task table from memory
             FA_HIP_TRY(hipMemcpyAsync(d_tasks, h_tasks.data(), h_tasks_bytes, hipMemcpyHostToDevice, st));
             FA_HIP_TRY(hipStreamSynchronize(st));
+            tasks_uploaded = true;
         }
         if (h8[4] != 0 && std::getenv("FLACARRAY_HIP_LATENCY_DEBUG"))
             std::fprintf(stderr, "flacarray_hip: latency decoder gave up (reasons %d) on a launch of %lld frames (first slice: stream %lld, sample %lld); repeating with K7\n",
@@ -668,6 +672,11 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
         }
     }
     if (!err_cleared) { FA_HIP_TRY(hipMemsetAsync(d_err, 0, 32, st)); err_cleared = true; }
+    if (inl.n > 0 && !tasks_uploaded) {  // no K7 launch ever sees a task table that only exists in kernel arguments
+        FA_HIP_TRY(hipMemcpyAsync(d_tasks, h_tasks.data(), h_tasks_bytes, hipMemcpyHostToDevice, st));
+        FA_HIP_TRY(hipStreamSynchronize(st));
+        tasks_uploaded = true;
+    }
 #ifndef FA_DEV_MINIMAL
     if (nch == 2) {
         // two-channel arrays: task-local planar image (low words), bit 32 of every sample, task status
@@ -756,6 +765,7 @@ int validate_range(int64_t stream_size, int64_t first_sample, int64_t last_sampl
 extern "C" {
 
 const char* fa_version(void) { return "flacarray_hip 0.1.0 (gfx950)"; }
+int fa_abi_version(void) { return FA_ABI_VERSION; }
 
 int fa_set_decode_verify(int on) {
     const bool was = g_verify.exchange(on != 0);
@@ -1817,14 +1827,34 @@ static int decode_host(const unsigned char* bytes, const int64_t* starts, const 
     const char* hv = std::getenv("FLACARRAY_HIP_HOST_VERIFY");
     const int host_verify = (hv && hv[0] == '0') ? 0 : 1;
     const size_t row_bytes = (size_t)n_decode * esz;
-    const int64_t chunk = host_chunk_streams(n_stream, row_bytes, 0x7fffffffLL);
-    const int64_t n_chunks = (n_stream + chunk - 1) / chunk;
+    // Chunks are bounded on BOTH sides: by decoded bytes (~256 MiB of output) and by the compressed bytes of their
+    // streams (~256 MiB of input) -- a short sample range over a large store (arr[:, 0:100]) has tiny rows and would
+    // otherwise put the whole store into one chunk.  Device memory in use: two input slots (one when there is a single
+    // chunk) + one output chunk, whatever the store's size.
+    const int64_t chunk = host_chunk_streams(n_stream, row_bytes, 0x7fffffffLL);  // (streams per chunk by output bytes)
+    int64_t in_target = 256ll << 20;
+    if (const char* e = std::getenv("FLACARRAY_HIP_HOST_CHUNK_BYTES")) {
+        const long long v = std::atoll(e);
+        if (v > 0) in_target = v;
+    }
+    std::vector<int64_t> cb;  // chunk c = streams [cb[c], cb[c + 1])
+    cb.push_back(0);
+    {
+        int64_t in_sum = 0;
+        for (int64_t s = 0; s < n_stream; ++s) {
+            const int64_t nbs = nbytes[s] > 0 ? nbytes[s] : 0;
+            if (s > cb.back() && (s - cb.back() >= chunk || in_sum + nbs > in_target)) { cb.push_back(s); in_sum = 0; }
+            in_sum += nbs;
+        }
+        cb.push_back(n_stream);
+    }
+    const int64_t n_chunks = (int64_t)cb.size() - 1;
 
-    // byte ranges of every chunk (host side, cheap), and the largest packed size: the two upload slots are that large
+    // byte ranges of every chunk (host side, cheap), and the largest packed size: the upload slots are that large
     std::vector<ChunkRanges> cr((size_t)n_chunks);
     int64_t max_packed = 0;
     for (int64_t c = 0; c < n_chunks; ++c) {
-        const int64_t s0 = c * chunk, ns = std::min(chunk, n_stream - s0);
+        const int64_t s0 = cb[(size_t)c], ns = cb[(size_t)c + 1] - s0;
         cr[(size_t)c].build(starts, nbytes, s0, ns);
         if (!cr[(size_t)c].ok || cr[(size_t)c].packed <= 0) return FA_ERROR_DECODE_INIT;
         max_packed = std::max(max_packed, cr[(size_t)c].packed);
@@ -1833,7 +1863,7 @@ static int decode_host(const unsigned char* bytes, const int64_t* starts, const 
     const size_t blob_slot = align_up((size_t)max_packed + 256, 256);
     const size_t aux_slot = align_up((size_t)chunk * 16 + 512, 256);
     int err = FA_ERROR_NONE;
-    if ((err = get_scratch(0, 2 * blob_slot, &d_blob2))) return err;
+    if ((err = get_scratch(0, (n_chunks > 1 ? 2 : 1) * blob_slot, &d_blob2))) return err;
     if ((err = get_scratch(4, 2 * aux_slot, &d_aux2))) return err;
     if ((err = get_scratch(5, (size_t)chunk * row_bytes * (nch == 2 ? 1 : 1) + 256, &d_out))) return err;
 
@@ -1844,7 +1874,7 @@ static int decode_host(const unsigned char* bytes, const int64_t* starts, const 
     FA_HTRACE("decode: populate started %.2f ms\n", (host_now() - t_enter) * 1e3);
 
     auto upload = [&, bytes, nbytes](int64_t c, int slot, hipStream_t st) -> int {
-        const int64_t s0 = c * chunk, ns = std::min(chunk, n_stream - s0);
+        const int64_t s0 = cb[(size_t)c], ns = cb[(size_t)c + 1] - s0;
         const ChunkRanges& r = cr[(size_t)c];
         char* db = reinterpret_cast<char*>(d_blob2) + (size_t)slot * blob_slot;
         for (const auto& pc : r.pieces)
@@ -1858,7 +1888,7 @@ static int decode_host(const unsigned char* bytes, const int64_t* starts, const 
     if (n_chunks > 1) err = feed.start(dev, n_chunks, upload, &ds_->feed_stream);
     FA_HTRACE("decode: set-up %.2f ms (entered at %.2f)\n", (host_now() - t_enter) * 1e3, t_enter * 1e3);
     for (int64_t c = 0; c < n_chunks && !err; ++c) {
-        const int64_t s0 = c * chunk, ns = std::min(chunk, n_stream - s0);
+        const int64_t s0 = cb[(size_t)c], ns = cb[(size_t)c + 1] - s0;
         const int slot = (int)(c & 1);
         if (n_chunks > 1) {
             if ((err = feed.wait_for(c))) break;

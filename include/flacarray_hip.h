@@ -254,6 +254,14 @@ int fa_device_count(void);
 /* library version string */
 const char* fa_version(void);
 
+/* ABI revision of the group-2 (fa_*) signatures in this header.  It is raised whenever an existing entry point changes
+ * its argument list (revision 2: the trailing `int verify` of the device decode entry points, 1 / 0 / negative = check /
+ * do not / process default, see fa_set_decode_verify); a binding built against
+ * another revision must refuse the library instead of calling it with a shifted argument list --
+ * flacarray_amd/_lib.py does. */
+#define FA_ABI_VERSION 2
+int fa_abi_version(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1100,6 +1100,9 @@ def test_host_abi_pipeline_many_chunks(fa, oracle, monkeypatch):
     assert np.array_equal(comp, blob_o) and np.array_equal(st, st_o) and np.array_equal(nb, nb_o)
     assert np.array_equal(fa.decode_flac(np.asarray(comp), st, nb, 20000), x)
     assert np.array_equal(fa.decode_flac(np.asarray(comp), st, nb, 20000, first_sample=4000, last_sample=9001), x[:, 4000:9001])
+    # a short sample range of every stream: rows of 400 B, so the chunks are cut by the COMPRESSED bytes of their
+    # streams (about five streams of ~46 KB per chunk here), not by the decoded bytes (which would make one chunk)
+    assert np.array_equal(fa.decode_flac(np.asarray(comp), st, nb, 20000, first_sample=4090, last_sample=4190), x[:, 4090:4190])
     pick = np.array([30, 2, 17, 3, 36, 0, 18])  # scattered and out of order: arbitrary starts / nbytes (decompress.c:194-313)
     assert np.array_equal(fa.decode_flac(np.asarray(comp), st[pick].copy(), nb[pick].copy(), 20000), x[pick])
     # more scattered byte ranges than one copy each is worth (> 2048 pieces): everything between the first and the last
@@ -1291,3 +1294,42 @@ def test_int64_side_right_decision(fa, oracle):
         assert {a for (i, a) in kinds if i == 0} == {9}, "tiny values of both signs: every frame side + right"
         assert {a for (i, a) in kinds if i in (1, 3)} == {1}, "no trial where the high word is zero or the low word large"
 
+
+
+@pytest.mark.parametrize("block", [8192, 16384])
+def test_few_slices_of_streams_with_large_blocks(fa, block):
+    """Foreign streams with blocks above 4096 samples (libFLAC writes them when asked to; the decoder takes up to
+    65535): K7L does not serve them, so a handful of slices -- whose task table would otherwise ride in K7L's kernel
+    arguments -- must reach K7 with the table in memory.  One-off calls and through a decode index, 1 to 8 slices."""
+    import torch
+
+    from tests.golden.make_golden import frame, stream
+
+    rng = np.random.default_rng(block)
+    n = 2 * block + 777
+    rows, blobs = [], []
+    for s in range(3):
+        x = (np.cumsum(rng.integers(-40, 41, n)) + 1000 * s).tolist()
+        frs = [frame(x[f * block : (f + 1) * block], f, 32, {"type": "fixed", "order": 1, "porder": 1, "params": [6, 6]} if f < 2 else
+                     {"type": "fixed", "order": 1, "porder": 0, "params": [6]}) for f in range(3)]
+        rows.append(x)
+        blobs.append(np.frombuffer(stream(frs, block, 32, n), dtype=np.uint8))
+    x = np.array(rows, dtype=np.int32)
+    nb = np.array([b.size for b in blobs], dtype=np.int64)
+    st = np.concatenate([[0], np.cumsum(nb)[:-1]]).astype(np.int64)
+    blob = np.concatenate(blobs)
+    dev = torch.device("cuda", 0)
+    tb, ts, tn = (torch.from_numpy(a).to(dev) for a in (blob, st, nb))
+    assert np.array_equal(fa.decode_flac_device(tb, ts, tn, n).cpu().numpy(), x)
+    idx = fa.DeviceDecodeIndex(tb, ts, tn, n)
+    for k in range(1, 9):
+        ss = rng.integers(0, 3, k)
+        cnt = rng.integers(1, 300, k)
+        first = np.array([rng.integers(0, n - c + 1) for c in cnt])
+        if k == 2:
+            first[0], cnt[0] = block - 5, 10  # across a frame boundary
+        for got, offs in (fa.decode_slices_device(tb, ts, tn, n, ss, first, cnt), idx.decode_slices(ss, first, cnt)):
+            flat = got.cpu().numpy()
+            for o, s_i, f0, c in zip(offs, ss, first, cnt):
+                assert np.array_equal(flat[o : o + c], x[s_i, f0 : f0 + c]), (k, s_i, f0, c)
+    idx.close()

@@ -22,10 +22,12 @@ def test_flacarray_nbytes_is_the_published_size(case):
     n_stream = int(np.prod(shape[:-1])) if len(shape) > 1 else 1
     assert f.nbytes - n_stream * P.own_stream_header(shape[-1], 5) == P.frame_bytes_published(P.SIZES[case]), where
     assert f.nbytes == published + 14 * n_stream
-    # and the reference's own bound on the round trip (tests/array.py:251-260: half a quantum)
+    # and the reference's own bound on the round trip (tests/array.py:251-260: half a quantum), plus the rounding of the
+    # quantisation's subtract / multiply and the restore's multiply / add at the magnitude of the data (4 eps |x|: with
+    # quanta 1e-8 on float32 values near 2 the float resolution, 1.2e-7, is what is left)
     back = f.to_array()
     quanta = kw["quanta"] if "quanta" in kw else (np.std(arr, axis=-1, keepdims=True) / 10 ** kw["precision"])
-    assert np.all(np.abs(back - arr) <= 0.5 * quanta * (1 + 1e-6) + np.abs(arr) * np.finfo(dtype).eps)
+    assert np.all(np.abs(back - arr) <= 0.5 * quanta + 4 * np.finfo(dtype).eps * np.abs(arr).max())
 
 
 def test_restored_values_of_cookbook_cell_12():
