@@ -64,6 +64,21 @@ def measured_traffic(kernel):
     return None
 
 
+def measured_mix(kernel):
+    """Instructions per wave of `kernel` from the newest committed PMC pass (profiles/r*_traffic.json, key
+    "instruction_mix"); None if there is none."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            for name, rec in json.load(open(path)).get("instruction_mix", {}).items():
+                if kernel in name:
+                    return dict(rec, source=os.path.basename(path))
+        except Exception:
+            continue
+    return None
+
+
 def measured_issue(kernel):
     """Issue-side picture of `kernel` from the newest committed PMC pass that has one (profiles/r*_traffic.json,
     key "issue": share of a wave's life spent issuing vector instructions x waves per SIMD); None if there is none."""
@@ -84,10 +99,30 @@ def cpu_baseline(n_samp, seconds_budget=25.0):
     sample of the same workload with every host core."""
     from oracle import oracle as O
 
-    # a one-GPU box gives this process a CPU share of 16 cores whatever the host's core count is
-    threads = min(O.lib().oracle_num_threads(), int(os.environ.get("FA_BENCH_CPU_THREADS", "16")))
+    # what this process may actually use: the scheduler affinity mask and the cgroup's CPU quota (a one-GPU box gives a
+    # share of the host, whatever os.cpu_count() says); the baseline runs on that many threads
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cpu_max = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                cpu_max = fh.read().strip()
+            if path.endswith("cfs_quota_us"):
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                    cpu_max = cpu_max + " " + fh.read().strip()
+            break
+        except OSError:
+            continue
+    quota_cpus = None
+    if cpu_max:
+        parts = cpu_max.split()
+        if len(parts) == 2 and parts[0] not in ("max", "-1"):
+            quota_cpus = max(1, int(float(parts[0]) / float(parts[1]) + 0.5))
+    usable = min(affinity, quota_cpus) if quota_cpus else affinity
+    threads = int(os.environ.get("FA_BENCH_CPU_THREADS", "0")) or usable
+    threads = max(1, min(threads, O.lib().oracle_num_threads(), 64))
     O.lib().oracle_set_threads(threads)
-    n_ch = 16 * threads  # ~15-20 s of CPU work at 16 threads
+    n_ch = 16 * threads  # ~15-20 s of CPU work whatever the thread count (16 channels of 2^20 samples per thread)
     rng = np.random.default_rng(123456789)
     t = np.arange(n_samp)
     f = 5.0 / n_samp
@@ -136,6 +171,8 @@ def cpu_baseline(n_samp, seconds_budget=25.0):
         "sample": f"{n_ch}ch x {n_samp} int32 sinusoid+noise, level 5, encode {x.size/(t1-t0)/1e6:.1f} + decode {x.size/(t2-t1)/1e6:.1f} Msamples/s",
         "cpu_model": cpu_model,
         "host_cores_visible": os.cpu_count(),
+        "affinity_cpus": affinity,
+        "cgroup_cpu_max": cpu_max,
         "threads_1": {"value": round(x1.size / (s2 - s0) / 1e6, 2), "unit": "Msamples/s",
                       "sample": f"16ch x {n_samp}, one thread: encode {x1.size/(s1-s0)/1e6:.1f} + decode {x1.size/(s2-s1)/1e6:.1f} Msamples/s"},
         "compiler": "gcc " + cflags,
@@ -256,8 +293,22 @@ def bench_end_to_end(fa, n_ch=512, n_samp=1 << 20, level=5):
         y = fa.decode_flac(np.asarray(comp), st, nb, n_samp)
         t2 = time.perf_counter()
     assert np.array_equal(y, x)
+    # the same decode into an array the caller already owns (its pages exist): what is left is PCIe, not the population
+    # of fresh host memory (profiles/r03_host_abi.md)
+    t3 = t4 = None
+    try:
+        from flacarray_amd.libflacarray import decode_flac_into
+
+        y[:] = 0
+        t3 = time.perf_counter()
+        decode_flac_into(np.asarray(comp), st, nb, n_samp, y)
+        t4 = time.perf_counter()
+        assert np.array_equal(y, x)
+    except ImportError:
+        pass
     return {
         "workload": f"{n_ch}ch x {n_samp} int32 ({x.nbytes / 2**30:.0f} GiB) numpy -> encode_flac -> numpy -> decode_flac -> numpy, PCIe included",
+        "decode_into_existing_array_Gsamples_per_s": round(x.size / (t4 - t3) / 1e9, 2) if t3 is not None else None,
         "encode_Gsamples_per_s": round(x.size / (t1 - t0) / 1e9, 2),
         "decode_Gsamples_per_s": round(x.size / (t2 - t1) / 1e9, 2),
         "encode_s": round(t1 - t0, 4),
@@ -384,7 +435,7 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         return int(flag.item()) == 0
 
-    def step(with_gather):
+    def step(with_gather, agree=False):
         comp, st, nb = fa.encode_flac_device(x, level=args.level, workspace=ws)
         pending = None
         if world > 1:
@@ -393,7 +444,7 @@ def main():
             # all-gather-v of the shard blobs over xGMI (one batched round of point-to-point transfers) on a side
             # stream, UNDER the decode of the same step, which needs only the local blob.
             if with_gather:
-                pending = fdist.assemble_global_async(comp, nb.reshape(-1), n_global)
+                pending = fdist.assemble_global_async(comp, nb.reshape(-1), n_global, agree=agree)
             else:
                 fdist.gather_stream_nbytes(nb.reshape(-1), n_global)
         y = fa.decode_flac_device(comp, st, nb, n_samp)
@@ -432,9 +483,12 @@ def main():
     compute_only = None
     if gather_state["on"]:
         # one rehearsal step decides, for all ranks together, whether the never-before-run RCCL leg is usable
+        # (agree=True: the ranks compare notes after their local preparations and before any transfer is queued, so a
+        # rank that cannot take part stops all of them there; a failure inside the transfers themselves ends through
+        # the watchdog)
         ok = True
         try:
-            step(True)
+            step(True, agree=True)
         except Exception as e:  # noqa: BLE001
             ok = False
             gather_state["error"] = f"{type(e).__name__}: {e}"[:300]
@@ -453,6 +507,27 @@ def main():
     # correctness of what was timed (outside the timed region)
     assert torch.equal(y, x), "decode(encode(x)) != x"
     c_bytes = comp.numel() / x.numel()
+
+    # the decode leg again with the frame CRC-16 check libFLAC performs (decompress.c:104-121): K9 beside K7 on a side
+    # stream (event pair 4 closes after both), and the unverified decode timed the same way right beside it
+    decode_verified = None
+    if rank == 0 and world == 1:
+        y = None
+        L.fa_profile_enable(1)
+        pair = {}
+        for vf in (False, True):
+            ms = []
+            for _ in range(4):
+                yv = fa.decode_flac_device(comp, st, nb, n_samp, verify=vf)
+                ms.append(profile_read(L)[4])
+            pair[vf] = float(np.mean(ms[1:]))
+            assert torch.equal(yv, x)
+            yv = None
+        L.fa_profile_enable(0)
+        decode_verified = {"ms": round(pair[True], 3), "Msamples_per_s": round(n_ch * n_samp / (pair[True] * 1e-3) / 1e6, 1),
+                           "unverified_ms_same_loop": round(pair[False], 3), "overhead": round(pair[True] / pair[False] - 1.0, 4),
+                           "what": "decode sequence with every frame's CRC-16 re-computed (K9 on a side stream beside K7), HIP events K6 .. both kernels done"}
+        y = fa.decode_flac_device(comp, st, nb, n_samp)
 
     cfg5 = cfg3 = None
     if not args.no_extra:
@@ -498,6 +573,12 @@ def main():
             kernels["compact_frames_kernel"] = {"ms": round(cmpm, 3), "algorithmic_GBs": round(2 * c_bytes * n_local / (cmpm * 1e-3) / 1e9, 1)}
         dom = max((enc_name, "decode_frames_kernel"), key=lambda k: kernels[k]["ms"])
         achieved = kernels[dom]["algorithmic_GBs"]
+        issue_floor = None
+        mix = measured_mix(dom)
+        if mix and mix.get("waves"):
+            # K3F: a wave per 4096-sample frame; K7: a wave per 64 frames -- either way waves scale with the samples
+            waves = mix["waves"] * (n_local / float(4096 * (1 << 20)))
+            issue_floor = round(mix["valu_per_wave"] * waves * 4.0 / 1024.0 / 2.4e9 * 1e3, 3)
         out = {
             "metric": "Msamples/s encode+decode, 4096ch x 1Msamp int32",
             "value": round(value, 1),
@@ -522,7 +603,10 @@ def main():
                                                           + (" + all-gather-v of the compressed blobs (global triple on every GPU)" if gather_state["on"] else "")))),
             },
             "roofline": {
-                "bound": "hbm",
+                # achieved / peak / frac are HBM figures (the contract's roofline for this path); `bound` names what
+                # actually limits the dominant kernel: the vector instruction stream ("issue": its own floor is
+                # issue_floor_ms, i.e. frac cannot pass issue_ceiling_frac whatever the memory system does) or HBM
+                "bound": "issue" if issue_floor is not None and issue_floor > alg_gb / HBM_PEAK_GBS * 1e3 else "hbm",
                 "kernel": dom,
                 "achieved": achieved,
                 "algorithmic_GB_per_launch": round(alg_gb, 3),
@@ -539,6 +623,11 @@ def main():
                 # shape (64 cache lines per load instruction) and the latency of the Rice chain do (profiles/r03_k7_experiments.md)
                 "limiter": "vector_issue" if dom != "decode_frames_kernel" else "per_lane_read_shape_and_latency",
                 "issue": measured_issue(dom),
+                # VALU per wave x waves x 4 cycles / (256 CUs x 4 SIMDs) / 2.4 GHz: the time the vector instructions of
+                # one launch take if every SIMD issues one of them every 4 cycles (instruction counts from the newest
+                # committed PMC pass, scaled to this run's number of frames)
+                "issue_floor_ms": issue_floor,
+                "issue_ceiling_frac": round(alg_gb / (issue_floor * 1e-3) / HBM_PEAK_GBS, 4) if issue_floor else None,
                 # the unit is the whole sequence -- HIP events around begin..finish (K3+K4+K5, host gaps
                 # included) and around K6+K7, on the launch stream
                 "encode_sequence": {"ms": round(enc_seq, 3), "achieved": gbs(enc_seq), "frac": round(gbs(enc_seq) / HBM_PEAK_GBS, 4) if enc_seq > 0 else None},
@@ -549,6 +638,8 @@ def main():
             "encode_Msamples_per_s": round(n_local * world / (enc_seq * 1e-3) / 1e6, 1) if enc_seq > 0 else None,
             "decode_Msamples_per_s": round(n_local * world / (dec_seq * 1e-3) / 1e6, 1) if dec_seq > 0 else None,
         }
+        if decode_verified is not None:
+            out["decode_verified"] = decode_verified
         if world > 1:
             ag = {"in_step": bool(gather_state["on"]), "overlapped_with_decode": bool(gather_state["on"] and backend == "nccl"),
                   "global_blob_bytes": gather_state["bytes"], "error": gather_state["error"]}

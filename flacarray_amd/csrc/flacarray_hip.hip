@@ -74,6 +74,10 @@ struct DeviceState {
     void* pin = nullptr;
     void* pin_dev = nullptr;
     bool pin_tried = false;
+    // the frame CRC-16 check of a large decode runs beside K7 on this stream (run_verify_beside)
+    hipStream_t verify_stream = nullptr;
+    hipEvent_t verify_ev[2] = {nullptr, nullptr};
+    bool verify_tried = false;
     // optional in-library kernel timing (HIP events on the launch stream), see fa_profile_enable
     // pairs: 0 K3 encode_frames, 1 K5 compact_frames, 2 K7 decode_frames, 3 whole encode sequence (begin .. finish),
     // 4 whole decode sequence (K6 + K7 + checks), 5 K1 float32_to_int32
@@ -351,6 +355,45 @@ int run_verify(const DecodeArgs& a, int* d_err, int* h_err, hipStream_t st, int 
     FA_HIP_TRY(hipMemcpyAsync(h_err, d_err, 16, hipMemcpyDeviceToHost, st));
     FA_HIP_TRY(hipStreamSynchronize(st));
     return FA_ERROR_NONE;
+}
+
+// The same check, issued BESIDE K7 instead of after it: K9 reads only the compressed bytes and the frame table, K7 is
+// bound by the latency of its Rice chain at two waves per SIMD and leaves half of the HBM bandwidth and a third of the
+// issue slots idle, and K9's waves (few registers) fit beside K7's.  begin: the side stream waits for everything queued
+// on `st` so far (K6's tables), then K9 is launched on it; end: `st` waits for K9.  Both kernels report through atomics
+// on the same status word.  The side stream has the lowest priority and K9 is queued AFTER K7 (queued first, its 262 144
+// small workgroups take every CU and K7 starts when they are done: 7.2 + 2.9 ms, measured).  begin returns false when the
+// side stream cannot be had: the caller then checks after K7 as before.
+bool run_verify_beside_begin(hipStream_t st) {
+    DeviceState* ds = dev_state();
+    if (!ds) return false;
+    if (!ds->verify_tried) {
+        ds->verify_tried = true;
+        hipStream_t vs = nullptr;
+        int least = 0, greatest = 0;  // (numerically: least priority = the larger number)
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&vs, hipStreamNonBlocking, least) == hipSuccess) {
+            if (hipEventCreateWithFlags(&ds->verify_ev[0], hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&ds->verify_ev[1], hipEventDisableTiming) == hipSuccess) {
+                ds->verify_stream = vs;
+            } else {
+                (void)hipStreamDestroy(vs);
+            }
+        }
+        if (!ds->verify_stream) (void)hipGetLastError();
+    }
+    if (!ds->verify_stream) return false;
+    if (hipEventRecord(ds->verify_ev[0], st) != hipSuccess) return false;
+    return hipStreamWaitEvent(ds->verify_stream, ds->verify_ev[0], 0) == hipSuccess;
+}
+// (called after K7 has been queued on `st`: K7's workgroups take the chip first, K9's fill what they leave)
+void run_verify_beside_launch(const DecodeArgs& a, hipStream_t st) {
+    DeviceState* ds = dev_state();
+    const uint16_t* tab = nullptr;
+    if (!ds || !ds->verify_stream || get_crc_tab_fused(&tab)) return;
+    hipLaunchKernelGGL(verify_crc16_kernel, dim3((unsigned)((a.n_tasks + 3) / 4)), dim3(256), 0, ds->verify_stream, a, tab);
+    (void)hipEventRecord(ds->verify_ev[1], ds->verify_stream);
+    (void)hipStreamWaitEvent(st, ds->verify_ev[1], 0);
 }
 
 constexpr size_t kPinBytes = 512u << 10;  // samples (larger results go by DMA: 1.6 MB took 307 us this way, 298 by copy); 64 bytes of status words follow
@@ -723,9 +766,17 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
     if ((rc = run_verify(a, d_err, h_err, st, verify))) return rc;
     return h_err[0] | (h_err[1] ? FA_ERROR_DECODE_PROCESS : 0);
 #else
+    // the frame CRC-16 check of a launch that fills the chip goes beside K7 (it needs what K6 built, nothing of K7's)
+    const bool verifying_k7 = (verify < 0 ? g_verify.load() : verify != 0);
+    const bool beside = verifying_k7 && a.n_tasks >= 16384 && std::getenv("FLACARRAY_HIP_VERIFY_AFTER") == nullptr &&
+                        run_verify_beside_begin(st);
     if (f32) hipLaunchKernelGGL((decode_frames_kernel<8, -1, true, 1>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
     else hipLaunchKernelGGL((decode_frames_kernel<8, -1, false, 1>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
     prof_end(2, st);
+    if (beside) {
+        run_verify_beside_launch(a, st);
+        verify = 0;  // (done: the check at the end of this function is not repeated)
+    }
     prof_end(4, st);  // (deeper-history passes, when a stream needs them, follow outside this pair)
     FA_HIP_TRY(hipMemcpyAsync(h_err, d_err, 16, hipMemcpyDeviceToHost, st));
     FA_HIP_TRY(hipStreamSynchronize(st));

@@ -36,22 +36,37 @@ __global__ __launch_bounds__(256) void verify_crc16_kernel(DecodeArgs a, const u
     const uint32_t L = (uint32_t)(end - start - 2);  // bytes covered by the CRC
     uint32_t crc_t = 0, last_end = 0;
     bool any = false;
-    for (uint32_t o = 4u * (uint32_t)lane; o < L; o += 256u) {
-        uint32_t w;
-        if (start + o + 4 <= a.blob_bytes) {
-            uint32_t raw;
-            __builtin_memcpy(&raw, p + o, 4);  // (any byte alignment)
-            w = __builtin_bswap32(raw);
-        } else {
-            w = 0;
-            for (uint32_t b = 0; b < 4 && start + o + b < a.blob_bytes; ++b) w |= (uint32_t)p[o + b] << (24 - 8 * b);
+    // Eight blocks of 256 bytes per trip: the eight loads of a lane are in flight together and the (serial, LDS-bound)
+    // folds follow -- one load per trip made the kernel wait for memory 37 times per frame (3.8 ms at cfg 2; K7 itself
+    // takes 7).  Words past L are zeros that are not folded.
+    constexpr int kBatch = 8;
+    for (uint32_t o0 = 4u * (uint32_t)lane; o0 < L; o0 += 256u * kBatch) {
+        uint32_t raw[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            const uint32_t o = o0 + 256u * (uint32_t)k;
+            raw[k] = 0;
+            if (o < L) {
+                if (start + o + 4 <= a.blob_bytes) {
+                    __builtin_memcpy(&raw[k], p + o, 4);  // (any byte alignment)
+                } else {  // the last bytes of the blob: byte by byte, in memory order
+                    for (uint32_t b = 0; b < 4 && start + o + b < a.blob_bytes; ++b) raw[k] |= (uint32_t)p[o + b] << (8 * b);
+                }
+            }
         }
-        if (o + 4u > L) w &= ~0u << (8u * (4u - (L - o)));  // bytes at and after L (the CRC itself) do not count
-        w ^= crc_t << 16;
-        crc_t = (uint32_t)crc_s[w >> 24] ^ (uint32_t)crc_s[256 + ((w >> 16) & 255u)] ^ (uint32_t)crc_s[512 + ((w >> 8) & 255u)] ^
-                (uint32_t)crc_s[768 + (w & 255u)];
-        last_end = o + 4u;
-        any = true;
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            const uint32_t o = o0 + 256u * (uint32_t)k;
+            if (o < L) {
+                uint32_t w = __builtin_bswap32(raw[k]);
+                if (o + 4u > L) w &= ~0u << (8u * (4u - (L - o)));  // bytes at and after L (the CRC itself) do not count
+                w ^= crc_t << 16;
+                crc_t = (uint32_t)crc_s[w >> 24] ^ (uint32_t)crc_s[256 + ((w >> 16) & 255u)] ^ (uint32_t)crc_s[512 + ((w >> 8) & 255u)] ^
+                        (uint32_t)crc_s[768 + (w & 255u)];
+                last_end = o + 4u;
+                any = true;
+            }
+        }
     }
     uint32_t contrib = 0;
     if (any) contrib = crc16_mulmod((uint16_t)crc_t, crc_tab[kFCrcSlice + ((int)L - (int)last_end) + 3]);

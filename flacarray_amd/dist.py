@@ -135,12 +135,17 @@ class _PendingAssembly:
         return float(self._events[0].elapsed_time(self._events[1]))
 
 
-def assemble_global_async(local_blob, local_nbytes, n_stream_global, group=None):
+def assemble_global_async(local_blob, local_nbytes, n_stream_global, group=None, agree=False):
     """assemble_global with the all-gather-v of the blobs issued on a side stream (RCCL): the caller can keep
     launching work that needs only its OWN shard -- the decode of the same step -- on the current stream and call
     `.wait()` where it needs the global triple.  The byte counts (32 KiB per rank) are gathered synchronously
     first: every rank needs them to size the receive buffer.  With gloo (CPU rehearsals) the transfers are host
-    transfers and complete inside this call; the handle then just returns the result."""
+    transfers and complete inside this call; the handle then just returns the result.
+
+    agree=True: after the local preparations (the receive buffer -- the one step that can fail on one rank alone) the
+    ranks all-reduce a failure flag and EVERY rank raises if any failed, BEFORE a transfer is queued: a rank that
+    dropped out after the others had queued their batch would leave their next collective behind a transfer that never
+    completes.  Costs one host synchronisation; meant for a rehearsal step (bench.py), not for the steady state."""
     import torch
     import torch.distributed as dist
 
@@ -153,7 +158,19 @@ def assemble_global_async(local_blob, local_nbytes, n_stream_global, group=None)
     offs = np.concatenate([[0], np.cumsum(rank_bytes)]).astype(np.int64)
     cur = torch.cuda.current_stream(dev)
     side = _side_stream(dev)
-    out = torch.empty(int(offs[-1]), dtype=torch.uint8, device=dev)  # (allocated on the current stream: freed there, too)
+    out, failure = None, None
+    try:
+        out = torch.empty(int(offs[-1]), dtype=torch.uint8, device=dev)  # (allocated on the current stream: freed there, too)
+    except Exception as e:  # noqa: BLE001
+        if not agree:
+            raise
+        failure = e
+    if agree:
+        flag = torch.tensor([0 if failure is None else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        if int(flag.item()):
+            raise RuntimeError("all-gather-v not started: a rank could not prepare its receive buffer"
+                               + (f" (this rank: {type(failure).__name__}: {failure})" if failure is not None else ""))
     side.wait_stream(cur)  # the payload is complete and `out` exists before the side stream touches either
     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     with torch.cuda.stream(side):

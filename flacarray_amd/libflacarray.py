@@ -377,6 +377,26 @@ def decode_flac(compressed, starts, nbytes, stream_size, first_sample=-1, last_s
     return flat_output.reshape(output_shape)
 
 
+def decode_flac_into(compressed, starts, nbytes, stream_size, out, first_sample=-1, last_sample=-1):
+    """`decode_flac` into an array the caller owns: the C boundary takes a caller-allocated output (decode_i32 /
+    decode_i64, flacarray.h:249-271; libflacarray.pyx:634 allocates a fresh one per call), and a caller that decodes
+    store after store into the same array pays for the transfer, not for the population of fresh pages.  `out`:
+    C-contiguous int32 / int64 of starts.size * n_decode elements."""
+    _lib.require_device()
+    n_decode = stream_size if (first_sample < 0 or last_sample < 0) else last_sample - first_sample
+    starts = np.ascontiguousarray(starts, dtype=np.int64).reshape(-1)
+    nbytes = np.ascontiguousarray(nbytes, dtype=np.int64).reshape(-1)
+    compressed = np.ascontiguousarray(compressed, dtype=np.uint8)
+    is64 = out.dtype == np.dtype(np.int64)
+    if out.dtype not in (np.dtype(np.int32), np.dtype(np.int64)) or not out.flags.c_contiguous or out.size != starts.size * n_decode:
+        raise RuntimeError("out must be a C-contiguous int32 / int64 array of starts.size x n_decode elements")
+    errcode = (_lib.lib().decode_i64 if is64 else _lib.lib().decode_i32)(
+        _ptr(compressed), _ptr(starts), _ptr(nbytes), int(starts.size), int(stream_size), int(first_sample), int(last_sample), _ptr(out), False)
+    if errcode != 0:
+        raise RuntimeError(f"Decoding failed, return code = {errcode}")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # Device-resident variants (torch tensors on the GPU; torch supplies memory and streams only)
 # ---------------------------------------------------------------------------------------------

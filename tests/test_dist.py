@@ -142,3 +142,62 @@ def test_owner_of_inverts_shard_range():
         for r in range(w):
             lo, hi = shard_range(n, w, r)
             assert np.all(o[lo:hi] == r)
+
+
+def _world8_worker(rank, world, port, n_ch, n_samp, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    from flacarray_amd import dist as fdist
+    from oracle import oracle as O
+
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x = sinusoid_noise_i32(n_ch, n_samp, seed=4)
+    lo, hi = fdist.shard_range(n_ch, world, rank)
+    blob, st, nb = O.encode_i32(x[lo:hi], 5)
+    g_blob, g_starts, g_nbytes = fdist.assemble_global(torch.from_numpy(blob), torch.from_numpy(nb), n_ch)
+    full_blob, full_st, full_nb = O.encode_i32(x, 5)
+    ok = np.array_equal(g_blob.numpy(), full_blob) and np.array_equal(g_starts.numpy(), full_st) and np.array_equal(g_nbytes.numpy(), full_nb)
+    # cfg 5 on the sharded store: owner routing of a replicated request table, outputs gathered back in request order
+    store = _StubStore(x[lo:hi])
+    rng = np.random.default_rng(987654321)
+    n = 400
+    ch = rng.integers(0, n_ch, n)
+    cnt = rng.integers(1, n_samp + 1, n)
+    first = np.array([rng.integers(0, n_samp - c + 1) for c in cnt])
+    idx, outs = fdist.route_slices(store, ch, first, cnt, n_ch)
+    ok = ok and all(lo <= ch[i] < hi for i in idx) and all(np.array_equal(o, x[ch[i], first[i] : first[i] + cnt[i]]) for i, o in zip(idx, outs))
+    allouts = fdist.route_slices(store, ch, first, cnt, n_ch, gather=True)
+    ok = ok and all(np.array_equal(o, x[c, f : f + k]) for o, c, f, k in zip(allouts, ch, first, cnt))
+    ret[rank] = (bool(ok), int(len(idx)), int(hi - lo))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_of_eight_with_an_uneven_stream_count():
+    """The shape of cfg 4 / cfg 5 at N = 8 (mpi.py:84-90,156-187): 32 771 streams do not divide by 8 -- np.array_split
+    gives the first three ranks 4097 streams --, every rank's shard blob has its own size, and the assembled triple must
+    still be the single-process encode byte for byte on every rank; requests are routed to the owners and come back in
+    request order.  (gloo on CPU, short streams; RCCL runs the same dist.py code on the node.)"""
+    import torch.multiprocessing as mp
+
+    world, n_ch = 8, 32771
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_world8_worker, args=(r, world, port, n_ch, 64, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    assert all(ret[r][0] for r in range(world))
+    assert sum(ret[r][1] for r in range(world)) == 400
+    assert [ret[r][2] for r in range(world)] == [4097, 4097, 4097, 4096, 4096, 4096, 4096, 4096]
