@@ -420,6 +420,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
     int order = 0, porder = 0, shift = 0, precision = 0;
     int kbest = 0;
     bool img_is_residual = false;  // the image holds (folded) residuals, warm-up samples excepted
+    bool win_small_l = false, win_small_f = false;  // the LPC / FIXED candidate's lane sums are all below 2^24
     int fo = -1;
     int32_t qkeep[MLO];
 #pragma unroll
@@ -587,6 +588,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
         int po_fix = 0, k_fix = 0;
         const int pmax_fix = pmax_for(fo < 0 ? 0 : fo);
         const bool small_fix = __all((fixA < (1u << 24)) && (fixB < (1u << 24)));
+        win_small_f = small_fix;
         const bool fuse_search = fo >= 0 && pmax_fix <= 5 && a.max_lpc_order > 0 && small_fix;
         uint64_t est_fix = 0;
         auto apply_fixed = [&]() __attribute__((always_inline)) {
@@ -761,7 +763,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
 #pragma unroll
                     for (int j = 0; j < MLO; ++j) qd[j] = (double)qreg[j] * scale;
                     // ---- P4: LPC residual in place (A in LDS, B in registers) + magnitude sums ----
-                    double tlA = 0.0, tlB = 0.0, mxr = 0.0;
+                    double tlA = 0.0, tlB = 0.0;
                     double hx[MLO];
                     // both histories are fetched before either half is overwritten
                     const int4 a7 = *reinterpret_cast<const int4*>(&smp[hist7]), a6 = *reinterpret_cast<const int4*>(&smp[hist6]);
@@ -771,6 +773,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
                     int4 b5 = make_int4(0, 0, 0, 0);
                     if constexpr (MLO > 8) b5 = hist_b(Bv[5], *reinterpret_cast<const int4*>(&smp[tailA5]));
                     lds_fence();
+                    // Per sample: MLO fma, floor, subtract, |r| into the lane sum, and the zig-zag fold taken in the double
+                    // domain -- trunc |2 r + 0.5| is 2 r for r >= 0 and -2 r - 1 for r < 0 (one fma and one conversion
+                    // instead of a conversion and three integer instructions).  A residual outside int32 (|r| >= 2^31,
+                    // which disqualifies the predictor) comes out as 0xffffffff, a value no valid residual folds to:
+                    // that is how the rare frame with such residuals is recognised below, without a per-sample maximum.
+                    auto fold_f64 = [&](double r) __attribute__((always_inline)) {
+                        return (int)(uint32_t)__builtin_fabs(__builtin_fma(r, 2.0, 0.5));
+                    };
                     auto res_group = [&](auto mask_tag, const int4& xv, int gi0, double& tl) __attribute__((always_inline)) {
                         constexpr bool MASK = decltype(mask_tag)::value;
                         const int xs[4] = {xv.x, xv.y, xv.z, xv.w};
@@ -794,15 +804,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
 #endif
                             if constexpr (MASK) {
                                 const bool v = (gi0 + e >= lo);
-                                const double ar = v ? fa_fabs(r) : 0.0;
-                                tl += ar;
-                                mxr = __builtin_fmax(mxr, ar);
-                                rs[e] = v ? rice_fold((int)r) : xs[e];
+                                tl += v ? fa_fabs(r) : 0.0;
+                                rs[e] = v ? fold_f64(r) : xs[e];
                             } else {
-                                const double ar = fa_fabs(r);
-                                tl += ar;
-                                mxr = __builtin_fmax(mxr, ar);
-                                rs[e] = rice_fold((int)r);
+                                tl += fa_fabs(r);
+                                rs[e] = fold_f64(r);
                             }
 #pragma unroll
                             for (int j = MLO - 1; j > 0; --j) hx[j] = hx[j - 1];
@@ -831,11 +837,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
                     }
                     FA_STAMP(7);
                     img_is_residual = true;
-                    const double MX = wave_max_f64(mxr);
                     const int pmax = pmax_for(lo);
                     int po_l = 0, k_l = 0;
                     uint64_t rbits;
-                    if (pmax <= 5 && __all((tlA < 16777216.0) && (tlB < 16777216.0))) {
+                    const bool small_l = __all((tlA < 16777216.0) && (tlB < 16777216.0));
+                    // every |r| is below its lane's sum: with small sums no residual leaves int32.  Otherwise (wide samples)
+                    // look for the mark of an out-of-range residual among the folded values (warm-up samples are not residuals)
+                    bool lpc_in_range = true;
+                    if (__builtin_expect(!small_l, 0)) {
+                        bool hit = false;
+#pragma unroll 1
+                        for (int t = 0; t < 8; ++t) {
+                            const int4 ra = *reinterpret_cast<const int4*>(&smp[K ^ (4 * t)]);
+                            const int ras[4] = {ra.x, ra.y, ra.z, ra.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) hit = hit || ((32 * lane + 4 * t + e >= lo) && (uint32_t)ras[e] == 0xffffffffu);
+                        }
+#pragma unroll
+                        for (int t = 0; t < 8; ++t)
+                            hit = hit || (uint32_t)Bv[t].x == 0xffffffffu || (uint32_t)Bv[t].y == 0xffffffffu || (uint32_t)Bv[t].z == 0xffffffffu ||
+                                  (uint32_t)Bv[t].w == 0xffffffffu;
+                        lpc_in_range = !__any(hit);
+                    }
+                    win_small_l = small_l;
+                    if (pmax <= 5 && small_l) {
                         SplitRiceSearch ls;
                         ls.start((uint32_t)tlA, (uint32_t)tlB, lo, pmax, lane);
                         ls.gather(); ls.params(); ls.totals();
@@ -845,7 +870,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
                     } else {
                         rbits = split_rice_search_slow((uint64_t)tlA, (uint64_t)tlB, lo, pmax, lane, &po_l, &k_l);
                     }
-                    if (MX <= 2147483647.0) {
+                    if (lpc_in_range) {
                         const uint64_t est = 8 + (uint64_t)wasted + 4 + 5 + (uint64_t)lo * (uint64_t)(prec + bps) + rbits;
                         if (est < best_bits) {
                             best_bits = est;
@@ -938,27 +963,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
         const uint32_t kB = (uint32_t)__builtin_amdgcn_ds_bpermute(pB << 2, kbest);
         const uint32_t cpp = 128u >> porder;  // chunks per partition
         uint32_t bitsA = 0, bitsB = 0;
-        auto size_group = [&](auto mask_tag, const int4& rv, uint32_t k, int gi0, uint32_t& acc) __attribute__((always_inline)) {
+        // quotient lengths.  A lane's magnitude sums below 2^24 (the usual case, known from the partition search) bound
+        // its 64 quotients by 2^25 in total: plain adds.  Otherwise every quotient is clamped (a code that long
+        // overflows its row anyway: the totals stay small and the row test below sends the frame to VERBATIM).
+        auto size_group = [&](auto mask_tag, auto clamp_tag, const int4& rv, uint32_t k, int gi0, uint32_t& acc) __attribute__((always_inline)) {
             constexpr bool MASK = decltype(mask_tag)::value;
+            constexpr bool CLAMP = decltype(clamp_tag)::value;
             const int rs[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const uint32_t u = (uint32_t)rs[e];  // (folded where the residual was computed)
-                uint32_t q = min(u >> k, 16384u);  // (a code this long overflows its row anyway: the sums stay small)
+                uint32_t q = u >> k;
+                if constexpr (CLAMP) q = min(q, 16384u);
                 if constexpr (MASK) q = (gi0 + e >= order) ? (q + k + 1u) : 0u;
                 acc += q;
             }
         };
         constexpr int kWarmGroupsS = (MLO + 3) / 4 > 1 ? (MLO + 3) / 4 : 1;  // (fixed orders <= 4 fit the first group)
+        auto size_lane = [&](auto clamp_tag) __attribute__((always_inline)) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int4 rv = *reinterpret_cast<const int4*>(&smp[K ^ (4 * t)]);
-            if (t < kWarmGroupsS) size_group(std::true_type{}, rv, kA, 32 * lane + 4 * t, bitsA);
-            else size_group(std::false_type{}, rv, kA, 0, bitsA);
-        }
+            for (int t = 0; t < 8; ++t) {
+                const int4 rv = *reinterpret_cast<const int4*>(&smp[K ^ (4 * t)]);
+                if (t < kWarmGroupsS) size_group(std::true_type{}, clamp_tag, rv, kA, 32 * lane + 4 * t, bitsA);
+                else size_group(std::false_type{}, clamp_tag, rv, kA, 0, bitsA);
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) size_group(std::false_type{}, clamp_tag, Bv[t], kB, 0, bitsB);
+        };
+        if (__builtin_expect((type == 3) ? win_small_l : win_small_f, 1)) size_lane(std::false_type{});
+        else size_lane(std::true_type{});
         bitsA += (8 - kWarmGroupsS) * 4 * (kA + 1u);
-#pragma unroll
-        for (int t = 0; t < 8; ++t) size_group(std::false_type{}, Bv[t], kB, 0, bitsB);
         bitsB += 32u * (kB + 1u);
         // partition parameters: the chunk that opens a partition carries them (partition 0 opens in chunk A_0)
         if (((uint32_t)lane & (cpp - 1u)) == 0u || cpp > 64u) {
@@ -1151,6 +1185,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
 #ifdef FA_STAMPS
         st_[14] += fa_memtime() - tq0_;  // (part of the flush calls: waiting for the frame's offset)
 #endif
+        // the frame's first block, once: its first dword may be partial (emit_word's byte-wise edges).  Kept out of the
+        // loop below, whose preheader would otherwise rebuild emit_word's lane masks and byte addresses at every call.
+        if (__builtin_expect(blocks_flushed == 0, 0)) {
+            uint32_t wv = ring[lane];
+            ring[lane] = 0;
+            if (lane == 0) { wv |= ring[kFRingWords]; ring[kFRingWords] = 0; }
+            crc_word(wv);
+            if (!dropped) emit_word((uint32_t)lane, wv);
+            blocks_flushed = 1;
+            __builtin_amdgcn_sched_barrier(0);
+        }
         while (blocks_flushed < done) {
             const uint32_t wi = (blocks_flushed * 64 + lane) & kFRingMask;
             uint32_t wv = ring[wi];
@@ -1159,10 +1204,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
                 if (lane == 0) { wv |= ring[kFRingWords]; ring[kFRingWords] = 0; }
             }
             crc_word(wv);
-            if (!dropped) {
-                if (__builtin_expect(blocks_flushed == 0, 0)) emit_word((uint32_t)lane, wv);
-                else emit_block(blocks_flushed, wv);
-            }
+            if (!dropped) emit_block(blocks_flushed, wv);
             blocks_flushed++;
         }
     };
