@@ -42,15 +42,10 @@ constexpr int kFSmpWords = 65 * 32;  // zero history chunk + 64 chunks of the fi
 constexpr int kFRingWords = FA_F_RING;
 constexpr int kFRingMask = kFRingWords - 1;
 constexpr int kFRingBlocks = kFRingWords / 64;
-// completed 256-byte blocks are written out once this many are pending: a larger ring delays the first flush -- the
-// point where the frame's byte offset must be known -- and always keeps room for the longest row (6 blocks) plus a
-// partial block
-#ifndef FA_F_ROW8
-#define FA_F_ROW8 1  // the row writer takes 8 samples per lane (rows of 512) instead of 4 (rows of 256)
-#endif
-constexpr int kFRowBlocks = FA_F_ROW8 ? 12 : 6;  // longest row in 256-byte blocks (two spec rows of 12288 bits each)
-constexpr int kFFlushHold = kFRingBlocks - kFRowBlocks - 1;
-static_assert(kFFlushHold >= 1, "the ring must hold the longest row and a partial block beside what waits to be flushed");
+// completed 256-byte blocks are written out when the next row would not fit beside them (flush_blocks): the first
+// flush is the point where the frame's byte offset must be known
+constexpr int kFRowBlocks = 12;  // longest row of the writer (512 samples: two spec rows of 12288 bits each) in 256-byte blocks
+static_assert(kFRingBlocks - kFRowBlocks - 1 >= 1, "the ring must hold the longest row and a partial block beside what waits to be flushed");
 constexpr int kFWaveWords = kFSmpWords + kFRingWords + 4 + 16;  // image, ring, mirror word (+pad), Rice parameter table
 constexpr int kFWaves = 4;                                      // wavefronts (frames) per workgroup
 constexpr int kFCrcSlice = 1024;                                // 4 x 256 transformed slicing tables (uint16)
@@ -63,6 +58,18 @@ constexpr int kFCrcXpow = 520;                                  // x^(8 (i - 255
 #endif
 #ifndef FA_F_CEIL
 #define FA_F_CEIL 0  // experiment (r02s): one instruction per sample fewer, yet slower in the same-box A/B
+#endif
+#ifndef FA_F_BFLY_N
+#define FA_F_BFLY_N 1  // the nine lag sums step by step side by side (one LDS round trip for all swizzles) instead of one after the other
+#endif
+#ifndef FA_F_PARKN
+#define FA_F_PARKN 32  // blocks that can wait in registers (an array of at most 32 registers is indexed in place, s_set_gpr_idx)
+#endif
+#ifndef FA_F_PARKBLK
+#define FA_F_PARKBLK 1  // completed blocks wait in registers, not the wave, while the frame's byte offset is unknown
+#endif
+#ifndef FA_F_PARK
+#define FA_F_PARK 1  // units 4..7 of the register image wait in the bit ring during the first half's lag products
 #endif
 #ifndef FA_F_WAVES
 #define FA_F_WAVES 3  // waves per SIMD the register allocation aims at
@@ -310,11 +317,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
     for (int i = tid; i < kFCrcSlice / 2; i += 256) reinterpret_cast<uint32_t*>(crc_s)[i] = reinterpret_cast<const uint32_t*>(a.crc_tab)[i];
     if (tid == 0) ticket_s = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (ticket_s == 0) {  // the scanner workgroup (the first one to start)
+    // (the ticket comes out of LDS, i.e. in a vector register: say that it is wave-uniform, so that the frame number, the
+    // stream, the source pointer and everything else derived from it live in scalar registers)
+    const uint32_t ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket_s);
+    if (ticket == 0) {  // the scanner workgroup (the first one to start)
         if (wave == 0) fused_scanner(a, lane);
         return;
     }
-    const int64_t g = (int64_t)(ticket_s - 1) * kFWaves + wave;
+    const int64_t g = (int64_t)(ticket - 1) * kFWaves + wave;
     if (g >= a.total_frames) return;
 
     int32_t* smp = lds_all + wave * kFWaveWords;
@@ -557,8 +567,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
         }
         FA_STAMP(1);
         {
-            const double T0 = wave_sum_butterfly(tot0), T1 = wave_sum_butterfly(tot1), T2 = wave_sum_butterfly(tot2),
-                         T3 = wave_sum_butterfly(tot3), T4 = wave_sum_butterfly(tot4);
+            double tsum[5] = {tot0, tot1, tot2, tot3, tot4};
+            wave_sum_butterfly_n<5>(tsum);
+            const double T0 = tsum[0], T1 = tsum[1], T2 = tsum[2], T3 = tsum[3], T4 = tsum[4];
             double M0 = 0.0, M1 = 0.0, M2 = 0.0, M3 = 0.0, M4 = 0.0;
             if (!narrow) {
                 M0 = wave_max_f64(mx0); M1 = wave_max_f64(mx1); M2 = wave_max_f64(mx2); M3 = wave_max_f64(mx3);
@@ -627,12 +638,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
             SplitRiceSearch fs;
             if (fuse_search) fs.start((uint32_t)fixA, (uint32_t)fixB, fo, pmax_fix, lane);
             double hist[MLO];
-            auto lag_group = [&](const int4& xv, const float4& wv) __attribute__((always_inline)) {
+            // (a table of doubles would save the conversion of the window value, one instruction per sample of twelve, but
+            // the doubled registers of the values in flight cost more in spills than that returns: scratch 32 -> 170 B)
+            struct WinV { double w[4]; };
+            auto load_win = [&](int i0) __attribute__((always_inline)) {
+                const float4 f = *reinterpret_cast<const float4*>(win + i0);
+                WinV v;
+                v.w[0] = (double)f.x; v.w[1] = (double)f.y; v.w[2] = (double)f.z; v.w[3] = (double)f.w;
+                return v;
+            };
+            auto lag_group = [&](const int4& xv, const WinV& wv) __attribute__((always_inline)) {
                 const int xs[4] = {xv.x, xv.y, xv.z, xv.w};
-                const float ws[4] = {wv.x, wv.y, wv.z, wv.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const double d = (double)xs[e] * (double)ws[e];
+                    const double d = (double)xs[e] * wv.w[e];
                     acc[0] = __builtin_fma(d, d, acc[0]);
 #pragma unroll
                     for (int j = 0; j < MLO; ++j) acc[j + 1] = __builtin_fma(d, hist[j], acc[j + 1]);
@@ -648,6 +667,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
                 if (tt == 5) fs.totals();
                 if (tt >= 7 && tt <= 12) fs.order(12 - tt);
             };
+#if FA_F_PARK
+            // Half of the register image (units 4..7 of B_l: 16 registers) waits in the idle bit ring while the lag products of
+            // the first half run -- the one place where the kernel's register demand peaks (nine accumulators, eight history
+            // values and the window values in doubles beside the 32 registers of B_l).  Left to itself the compiler
+            // spills exactly these 16 registers to scratch there, i.e. to memory; the ring is LDS and idle until the writer.
+            {
+                int4* const pk = reinterpret_cast<int4*>(ring) + lane;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) pk[64 * t] = Bv[4 + t];
+            }
+#endif
             {   // half A: samples 32 l + ..., history = the MLO samples before (zero for lane 0)
                 const int g0 = 32 * lane;
                 const int4 h7 = *reinterpret_cast<const int4*>(&smp[hist7]), h6 = *reinterpret_cast<const int4*>(&smp[hist6]);
@@ -661,9 +691,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
                 // window values four groups at a time (16 registers in flight, not 32: the kernel lives at 168)
 #pragma unroll
                 for (int tb = 0; tb < 8; tb += FA_F_WBATCH) {
-                    float4 wv[FA_F_WBATCH];
+                    WinV wv[FA_F_WBATCH];
 #pragma unroll
-                    for (int t = 0; t < FA_F_WBATCH; ++t) wv[t] = *reinterpret_cast<const float4*>(win + g0 + 4 * (tb + t));
+                    for (int t = 0; t < FA_F_WBATCH; ++t) wv[t] = load_win(g0 + 4 * (tb + t));
 #pragma unroll
                     for (int t = 0; t < FA_F_WBATCH; ++t) {
                         lag_group(*reinterpret_cast<const int4*>(&smp[K ^ (4 * (tb + t))]), wv[t]);
@@ -672,6 +702,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#if FA_F_PARK
+            {   // (the address passes through an asm that also takes the last accumulator: the reads cannot move above half A)
+                uint32_t pin = 16u * (uint32_t)lane;
+                asm volatile("" : "+v"(pin) : "v"(__double2loint(acc[MLO])));
+                const int4* const pk = reinterpret_cast<const int4*>(reinterpret_cast<const char*>(ring) + pin);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) Bv[4 + t] = pk[64 * t];
+            }
+#endif
             {   // half B
                 const int g0 = 2048 + 32 * lane;
                 const int4 h7 = hist_b(Bv[7], *reinterpret_cast<const int4*>(&smp[tailA7]));
@@ -683,9 +722,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
                 for (int j = 0; j < MLO; ++j) hist[j] = (double)hs[j] * (double)win[g0 - 1 - j];
 #pragma unroll
                 for (int tb = 0; tb < 8; tb += FA_F_WBATCH) {
-                    float4 wv[FA_F_WBATCH];
+                    WinV wv[FA_F_WBATCH];
 #pragma unroll
-                    for (int t = 0; t < FA_F_WBATCH; ++t) wv[t] = *reinterpret_cast<const float4*>(win + g0 + 4 * (tb + t));
+                    for (int t = 0; t < FA_F_WBATCH; ++t) wv[t] = load_win(g0 + 4 * (tb + t));
 #pragma unroll
                     for (int t = 0; t < FA_F_WBATCH; ++t) {
                         lag_group(Bv[tb + t], wv[t]);
@@ -702,8 +741,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
                 apply_fixed();
             }
             double autoc[MLO + 1];
+#if FA_F_BFLY_N
+#pragma unroll
+            for (int j = 0; j <= MLO; ++j) autoc[j] = acc[j];
+            wave_sum_butterfly_n<MLO + 1>(autoc);
+#else
 #pragma unroll
             for (int j = 0; j <= MLO; ++j) autoc[j] = wave_sum_butterfly(acc[j]);
+#endif
 
             FA_STAMP(5);
             if (__builtin_expect(autoc[0] != 0.0, 1)) {
@@ -891,6 +936,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
     }
 
     FA_STAMP(8);
+    // (the lane number of the writer half of the kernel is a fresh copy: the one taken at the top would otherwise stay
+    // alive across the register peak of the lag loops, and the compiler keeps it in scratch memory there)
+    const int lane_w = lane_id_opaque();
     // ---- materialise the winner's residual: LPC is in place; FIXED is recomputed from the samples -------
     auto reload_image = [&]() __attribute__((always_inline)) {
         FA_IMAGE_ADDRS;
@@ -941,7 +989,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
 #pragma unroll 1
             for (int t = 0; t < 8; ++t) {
                 int4* px = reinterpret_cast<int4*>(&smp[K ^ (4 * t)]);
-                *px = fgroup(*px, 32 * lane + 4 * t);
+                *px = fgroup(*px, 32 * lane_w + 4 * t);
             }
             x1 = hb2.w; x2 = hb2.z; x3 = hb2.y; x4 = hb2.x;
 #pragma unroll
@@ -951,19 +999,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
         lds_fence();
     }
 
-    // ---- exact size of the winner (Rice parameters are uniform over a lane's chunk), VERBATIM fallback ----
+    // ---- exact size of the winner (Rice parameters are uniform over a lane_w's chunk), VERBATIM fallback ----
     bool rice2 = false;
-    if (type >= 2) rice2 = __any((lane < (1 << porder)) && (kbest >= 15));
+    if (type >= 2) rice2 = __any((lane_w < (1 << porder)) && (kbest >= 15));
     const int plen = rice2 ? 5 : 4;
     uint32_t sub_bits;  // bits of the subframe
     if (type >= 2) {
         FA_IMAGE_ADDRS;
-        const int pA = (lane << porder) >> 7, pB = ((64 + lane) << porder) >> 7;
+        const int pA = (lane_w << porder) >> 7, pB = ((64 + lane_w) << porder) >> 7;
         const uint32_t kA = (uint32_t)__builtin_amdgcn_ds_bpermute(pA << 2, kbest);
         const uint32_t kB = (uint32_t)__builtin_amdgcn_ds_bpermute(pB << 2, kbest);
         const uint32_t cpp = 128u >> porder;  // chunks per partition
         uint32_t bitsA = 0, bitsB = 0;
-        // quotient lengths.  A lane's magnitude sums below 2^24 (the usual case, known from the partition search) bound
+        // quotient lengths.  A lane_w's magnitude sums below 2^24 (the usual case, known from the partition search) bound
         // its 64 quotients by 2^25 in total: plain adds.  Otherwise every quotient is clamped (a code that long
         // overflows its row anyway: the totals stay small and the row test below sends the frame to VERBATIM).
         auto size_group = [&](auto mask_tag, auto clamp_tag, const int4& rv, uint32_t k, int gi0, uint32_t& acc) __attribute__((always_inline)) {
@@ -984,7 +1032,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const int4 rv = *reinterpret_cast<const int4*>(&smp[K ^ (4 * t)]);
-                if (t < kWarmGroupsS) size_group(std::true_type{}, clamp_tag, rv, kA, 32 * lane + 4 * t, bitsA);
+                if (t < kWarmGroupsS) size_group(std::true_type{}, clamp_tag, rv, kA, 32 * lane_w + 4 * t, bitsA);
                 else size_group(std::false_type{}, clamp_tag, rv, kA, 0, bitsA);
             }
 #pragma unroll
@@ -995,9 +1043,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
         bitsA += (8 - kWarmGroupsS) * 4 * (kA + 1u);
         bitsB += 32u * (kB + 1u);
         // partition parameters: the chunk that opens a partition carries them (partition 0 opens in chunk A_0)
-        if (((uint32_t)lane & (cpp - 1u)) == 0u || cpp > 64u) {
+        if (((uint32_t)lane_w & (cpp - 1u)) == 0u || cpp > 64u) {
             if (cpp <= 64u) { bitsA += (uint32_t)plen; bitsB += (uint32_t)plen; }
-            else if (lane == 0) bitsA += (uint32_t)plen;
+            else if (lane_w == 0) bitsA += (uint32_t)plen;
         }
         // row totals (8 lanes per row) against the row cap, frame total
         uint32_t rA = bitsA, rB = bitsB;
@@ -1027,19 +1075,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
     // diagnostic build: the optional FrameInfo record carries 100 MHz timestamps instead of the decisions
     // (wasted = start, shift = size published, porder = offset out (written by the scanner), precision = offset asked
     // for, blocksize = offset seen)
-    if (lane == 0 && a.info) {
+    if (lane_w == 0 && a.info) {
         a.info[g].wasted = (int32_t)tl_start_;
         a.info[g].shift = (int32_t)(uint32_t)__builtin_amdgcn_s_memrealtime();
         __builtin_amdgcn_s_waitcnt(0);
     }
 #endif
-    if (lane == 0) {
+    if (lane_w == 0) {
         __hip_atomic_store(a.size_pub + gu, 0x80000000u | total_bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         a.frame_bytes[g] = total_bytes;
     }
     (void)F;
 #ifndef FA_TIMELINE
-    if (lane == 0 && a.info) {
+    if (lane_w == 0 && a.info) {
         FrameInfo fi;
         fi.type = type;
         fi.order = (type >= 2) ? order : 0;
@@ -1056,19 +1104,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
 #ifdef FA_F_ANALYSIS_ONLY  // timing experiment: what the analysis (everything up to the published size) costs on its own
     // (no frame is written; frame_abs gets the frame's SLOT position, so that the stream-header kernel that follows
     // stays inside the capacity buffer -- an unset frame_abs would send it out of bounds)
-    if (lane == 0) a.frame_abs[g] = g * (int64_t)kSlotBytes + (s + 1) * a.hb;
+    if (lane_w == 0) a.frame_abs[g] = g * (int64_t)kSlotBytes + (s + 1) * a.hb;
     return;
 #endif
     // ---- writer state ------------------------------------------------------------------------------------
-    kpar[lane] = (uint8_t)kbest;
-    for (int i = lane; i < kFRingWords; i += 64) ring[i] = 0;
-    if (lane == 0) ring[kFRingWords] = 0;
+    kpar[lane_w] = (uint8_t)kbest;
+    for (int i = lane_w; i < kFRingWords; i += 64) ring[i] = 0;
+    if (lane_w == 0) ring[kFRingWords] = 0;
     lds_fence();
     uint32_t pos = 0;
     uint32_t blocks_flushed = 0;
     uint8_t* dst = nullptr;  // final position of the frame, known after the look-back
     bool dropped = false, have_dst = false;
-    uint32_t crc_t = 0;  // this lane's running CRC state (transformed domain, see crc tables)
+    uint32_t crc_t = 0;  // this lane_w's running CRC state (transformed domain, see crc tables)
 
     auto put_bits = [&](uint32_t P, uint32_t val, uint32_t nb) __attribute__((always_inline)) {
         const uint32_t off = P & 31u;
@@ -1113,7 +1161,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
         }
 #endif
 #ifdef FA_TIMELINE
-        if (lane == 0 && a.info) {
+        if (lane_w == 0 && a.info) {
             a.info[g].precision = (int32_t)tl_req_;
             a.info[g].blocksize = (int32_t)(uint32_t)__builtin_amdgcn_s_memrealtime();
         }
@@ -1121,35 +1169,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
 #ifdef FA_STAMPS
         st_[3] += spins;                 // polls
 #endif
-        // (every lane loaded the same word: say so, the destination then lives in scalar registers)
+        // (every lane_w loaded the same word: say so, the destination then lives in scalar registers)
         const int64_t off = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(off_word >> 32)) << 32) |
                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off_word));
         fail = __builtin_amdgcn_readfirstlane((int)fail) != 0;
         if (fail || off < 0 || off + (int64_t)total_bytes > a.capacity) {
-            if (lane == 0) atomicOr(a.err, fail ? 2 : 1);
+            if (lane_w == 0) atomicOr(a.err, fail ? 2 : 1);
             dropped = true;  // the frame is not written; the host reports the error
         } else {
             dst = a.blob + off;
-            if (lane == 0) a.frame_abs[g] = off;
+            if (lane_w == 0) a.frame_abs[g] = off;
         }
         have_dst = true;
     };
-    // CRC-16 over interleaved words: every lane folds its word of each 256-byte block; the old state enters through
+    // CRC-16 over interleaved words: every lane_w folds its word of each 256-byte block; the old state enters through
     // the top half of the word (tables pre-multiplied by x^2016, so that equals advancing it by 256 bytes)
     auto crc_word = [&](uint32_t wv) __attribute__((always_inline)) {
         const uint32_t w = wv ^ (crc_t << 16);
-        crc_t = (uint32_t)crc_s[w >> 24] ^ (uint32_t)crc_s[256 + ((w >> 16) & 255u)] ^ (uint32_t)crc_s[512 + ((w >> 8) & 255u)] ^
-                (uint32_t)crc_s[768 + (w & 255u)];
+        const uint32_t t0 = crc_s[w >> 24], t1 = crc_s[256 + ((w >> 16) & 255u)], t2 = crc_s[512 + ((w >> 8) & 255u)], t3 = crc_s[768 + (w & 255u)];
+        // (the four table entries are zero-extended 16-bit loads: full-width xors keep the state clean without the
+        // 16-bit operation + mask the compiler otherwise emits)
+        uint32_t x01;
+        asm("v_xor_b32 %0, %1, %2" : "=v"(x01) : "v"(t0), "v"(t1));
+        asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(crc_t) : "v"(x01), "v"(t2), "v"(t3));
     };
     // Stores are destination-ALIGNED dwords (an unaligned dword store becomes partial-line writes: the first version
     // wrote 2.6x the blob's bytes to the fabric, profiles/r02h_traffic.json).  The frame starts at dst, sh = dst & 3
     // bytes past a dword boundary; aligned dword m (address dst - sh + 4 m) holds stream bytes [4 m - sh, 4 m - sh + 4),
     // i.e. the last sh bytes of ring word m - 1 and the first 4 - sh of ring word m (big-endian words: one v_alignbit).
-    // Lane l takes word m - 1 from lane l - 1 (DPP), lane 0 from `carry`, the last word of the previous block.  Dwords
+    // Lane l takes word m - 1 from lane_w l - 1 (DPP), lane_w 0 from `carry`, the last word of the previous block.  Dwords
     // that reach outside the frame's bytes [0, total_bytes) -- its first and last -- are written byte by byte: the
     // neighbouring frames own the rest of them.
     uint32_t carry = 0;
-    auto emit_word = [&](uint32_t m, uint32_t Q) __attribute__((always_inline)) {  // all lanes: ring word m = m0 + lane (0 beyond the frame)
+    auto emit_word = [&](uint32_t m, uint32_t Q) __attribute__((always_inline)) {  // all lanes: ring word m = m0 + lane_w (0 beyond the frame)
         const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u);
         const uint32_t P = (uint32_t)dpp_wave_shr1((int)carry, (int)Q);
         carry = (uint32_t)__builtin_amdgcn_readlane((int)Q, 63);
@@ -1172,43 +1224,102 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
         const uint32_t P = (uint32_t)dpp_wave_shr1((int)carry, (int)Q);
         carry = (uint32_t)__builtin_amdgcn_readlane((int)Q, 63);
         const uint32_t V = __builtin_amdgcn_alignbit(P, Q, 8u * sh);
-        *reinterpret_cast<uint32_t*>(dst - sh + 256u * blk + 4u * (uint32_t)lane) = __builtin_bswap32(V);
+        *reinterpret_cast<uint32_t*>(dst - sh + 256u * blk + 4u * (uint32_t)lane_w) = __builtin_bswap32(V);
     };
-    auto flush_blocks = [&]() __attribute__((always_inline)) {
+    // Called BEFORE a row is written, with the row's exact length (the scan has it before the first code is placed):
+    // completed blocks leave the ring only when the row would not fit beside them -- the first bit after the row must stay
+    // less than a ring away from the oldest block still held (which also keeps the mirror word to one straddling code at
+    // a time).
+    //
+    // Where they go depends on whether the frame's byte offset is known yet.  It usually is not when the ring first
+    // fills up: the offset needs every frame before this one to have published its size, and among the ~3000 frames in
+    // flight some straggler is always ~8 us behind ("the wait").  Instead of waiting there, the frame moves
+    // its completed blocks -- CRC folded on the way -- into REGISTERS: one block is one register across the wave, the
+    // analysis is over and a third of the register file is idle, so 32 blocks (8 KB; with the ring 12 KB, more than an
+    // average frame) cost no memory traffic and no LDS.  The offset word is polled without waiting: a load issued at
+    // one call is looked at by the next.  Once it is there the parked blocks are stored first, in order (the carry of
+    // the destination-aligned stores runs through them), and the rest goes straight from the ring as before.  Only a
+    // frame that has run out of registers as well, or has nothing left to do, spins.
+#if FA_F_PARKBLK
+    uint32_t park[FA_F_PARKN];
+#endif
+    uint32_t n_parked = 0;
+    auto take_block = [&](uint32_t blk) __attribute__((always_inline)) {  // ring block blk -> word per lane_w, slot cleared
+        const uint32_t wi = (blk * 64 + lane_w) & kFRingMask;
+        uint32_t wv = ring[wi];
+        ring[wi] = 0;
+        if (__builtin_expect((blk & (uint32_t)(kFRingBlocks - 1)) == 0, 0)) {
+            if (lane_w == 0) { wv |= ring[kFRingWords]; ring[kFRingWords] = 0; }
+        }
+        return wv;
+    };
+    auto flush_blocks = [&](uint32_t row_bits, bool final_call) __attribute__((always_inline)) {
         const uint32_t done = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pos >> 11));
         blocks_flushed = (uint32_t)__builtin_amdgcn_readfirstlane((int)blocks_flushed);
-        if (done - blocks_flushed < (uint32_t)kFFlushHold) return;
+        const uint32_t hi_blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)((pos + row_bits) >> 11));
+        if (!final_call && hi_blk - blocks_flushed < (uint32_t)kFRingBlocks) return;
 #ifdef FA_STAMPS
         const unsigned long long tq0_ = fa_memtime();
 #endif
-        if (!have_dst) lb_resolve();
+        if (!have_dst) {
+#if FA_F_PARKBLK
+            if (!final_call && off_word == 0) {  // (the load issued at the previous call, or at publish time)
+                off_word = lb_load(a.off_pub + gu);  // looked at by the next call
+                n_parked = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_parked);
+                while (blocks_flushed < done && n_parked < (uint32_t)FA_F_PARKN) {
+                    const uint32_t wv = take_block(blocks_flushed);
+                    crc_word(wv);
+                    park[n_parked] = wv;
+                    n_parked++;
+                    blocks_flushed++;
+                }
+                if (hi_blk - blocks_flushed < (uint32_t)kFRingBlocks) {
+#ifdef FA_STAMPS
+                    st_[14] += fa_memtime() - tq0_;
+#endif
+                    return;  // the row fits now
+                }
+            }
+#endif
+            lb_resolve();
+        }
 #ifdef FA_STAMPS
         st_[14] += fa_memtime() - tq0_;  // (part of the flush calls: waiting for the frame's offset)
 #endif
+#if FA_F_PARKBLK
+        // the parked blocks first: blocks 0 .. n_parked - 1 of the frame
+        n_parked = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_parked);
+        if (__builtin_expect(n_parked != 0, 0)) {
+            if (!dropped) {
+                emit_word((uint32_t)lane_w, park[0]);  // (the frame's first dword may be partial: byte-wise edges)
+                for (uint32_t i = 1; i < n_parked; ++i) emit_block(i, park[i]);
+            }
+            n_parked = 0;
+        }
+#endif
         // the frame's first block, once: its first dword may be partial (emit_word's byte-wise edges).  Kept out of the
-        // loop below, whose preheader would otherwise rebuild emit_word's lane masks and byte addresses at every call.
-        if (__builtin_expect(blocks_flushed == 0, 0)) {
-            uint32_t wv = ring[lane];
-            ring[lane] = 0;
-            if (lane == 0) { wv |= ring[kFRingWords]; ring[kFRingWords] = 0; }
+        // loop below, whose preheader would otherwise rebuild emit_word's lane_w masks and byte addresses at every call.
+        if (__builtin_expect(blocks_flushed == 0 && done > 0, 0)) {
+            const uint32_t wv = take_block(0);
             crc_word(wv);
-            if (!dropped) emit_word((uint32_t)lane, wv);
+            if (!dropped) emit_word((uint32_t)lane_w, wv);
             blocks_flushed = 1;
             __builtin_amdgcn_sched_barrier(0);
         }
         while (blocks_flushed < done) {
-            const uint32_t wi = (blocks_flushed * 64 + lane) & kFRingMask;
-            uint32_t wv = ring[wi];
-            ring[wi] = 0;
-            if (__builtin_expect((blocks_flushed & (uint32_t)(kFRingBlocks - 1)) == 0, 0)) {
-                if (lane == 0) { wv |= ring[kFRingWords]; ring[kFRingWords] = 0; }
-            }
+            const uint32_t wv = take_block(blocks_flushed);
             crc_word(wv);
             if (!dropped) emit_block(blocks_flushed, wv);
             blocks_flushed++;
         }
     };
 
+#if FA_F_PARKBLK
+    // (the registers of `park` begin their life HERE, with whatever they hold: left undefined, the compiler carries the
+    // "value" of the array from the top of the kernel and spills part of it around the analysis)
+#pragma unroll
+    for (int i = 0; i < FA_F_PARKN; ++i) asm volatile("" : "=v"(park[i]));
+#endif
     lb_issue();
     // ---- preamble: frame header, subframe header, warm-up, LPC fields, residual header ------------------
     {
@@ -1219,31 +1330,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
         constexpr int kL_warm = 6, kL_lpc = kL_warm + kWarmLanes, kL_coef = kL_lpc + 1, kL_rice = kL_coef + MLO;
         static_assert(kL_rice < 64, "preamble fields must fit the wave");
         uint32_t fv = 0, fnb = 0;
-        if (lane == 0) { fv = fhe.x; fnb = 32; }
-        else if (lane == 1) { fv = fhe.y; fnb = (fhe.w >> 8) & 0xFFu; }
-        else if (lane == 2) { fv = fhe.z & 0xFFFFu; fnb = (fhe.w >> 16) & 0xFFu; }
-        else if (lane == 3) { fv = fhe.z >> 16; fnb = fhe.w >> 24; }
-        else if (lane == 4) { fv = ((fhe.w & 0xFFu) << 8) | (uint32_t)((tc << 1) | (wasted ? 1 : 0)); fnb = 16; }
-        else if (lane == 5) { if (wasted) { fv = 1; fnb = (uint32_t)wasted; } }
-        else if (lane < kL_lpc) {
-            if (lane - kL_warm < nwarm) {
+        if (lane_w == 0) { fv = fhe.x; fnb = 32; }
+        else if (lane_w == 1) { fv = fhe.y; fnb = (fhe.w >> 8) & 0xFFu; }
+        else if (lane_w == 2) { fv = fhe.z & 0xFFFFu; fnb = (fhe.w >> 16) & 0xFFu; }
+        else if (lane_w == 3) { fv = fhe.z >> 16; fnb = fhe.w >> 24; }
+        else if (lane_w == 4) { fv = ((fhe.w & 0xFFu) << 8) | (uint32_t)((tc << 1) | (wasted ? 1 : 0)); fnb = 16; }
+        else if (lane_w == 5) { if (wasted) { fv = 1; fnb = (uint32_t)wasted; } }
+        else if (lane_w < kL_lpc) {
+            if (lane_w - kL_warm < nwarm) {
                 // warm-up samples are original samples: the residual passes leave them in place; a constant frame's
                 // sample comes from the image as staged
-                fv = (uint32_t)smp[fsmp_idx(lane - kL_warm)] & smask;
+                fv = (uint32_t)smp[fsmp_idx(lane_w - kL_warm)] & smask;
                 fnb = (uint32_t)bps;
             }
         }
-        else if (lane == kL_lpc) { if (type == 3) { fv = ((uint32_t)(precision - 1) << 5) | (uint32_t)shift; fnb = 9; } }
-        else if (lane < kL_rice) {
-            if (type == 3 && lane - kL_coef < order) {
+        else if (lane_w == kL_lpc) { if (type == 3) { fv = ((uint32_t)(precision - 1) << 5) | (uint32_t)shift; fnb = 9; } }
+        else if (lane_w < kL_rice) {
+            if (type == 3 && lane_w - kL_coef < order) {
                 int32_t q = 0;
 #pragma unroll
-                for (int j = 0; j < MLO; ++j) q = (lane - kL_coef == j) ? qkeep[j] : q;
+                for (int j = 0; j < MLO; ++j) q = (lane_w - kL_coef == j) ? qkeep[j] : q;
                 fv = (uint32_t)q & ((1u << precision) - 1u);
                 fnb = (uint32_t)precision;
             }
         }
-        else if (lane == kL_rice) { if (type >= 2) { fv = ((rice2 ? 1u : 0u) << 4) | (uint32_t)porder; fnb = 6; } }
+        else if (lane_w == kL_rice) { if (type >= 2) { fv = ((rice2 ? 1u : 0u) << 4) | (uint32_t)porder; fnb = 6; } }
         const uint32_t incl = wave_incl_scan_u32(fnb);
         if (fnb) put_bits(incl - fnb, fv, fnb);
         pos = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -1259,99 +1370,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
         for (int j = 0; j < 16; ++j) {
             const int4 rv = load_row(j);
             const int rs[4] = {rv.x >> wasted, rv.y >> wasted, rv.z >> wasted, rv.w >> wasted};
-            uint32_t p = pos + (uint32_t)(4 * bps) * (uint32_t)lane;
+            flush_blocks((uint32_t)(256 * bps), false);
+            uint32_t p = pos + (uint32_t)(4 * bps) * (uint32_t)lane_w;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 put_bits(p, (uint32_t)rs[e] & mask, (uint32_t)bps);
                 p += (uint32_t)bps;
             }
             pos += (uint32_t)(256 * bps);
-            flush_blocks();
         }
     } else if (type >= 2) {
         FA_IMAGE_ADDRS;
         const uint32_t ps = (uint32_t)(bs >> porder);
         const int l2ps = 12 - porder;
-        struct RowPrep {
-            uint32_t u[4], q[4], k, lane_len, incl, total;
-            bool newp;
-        };
         // row j (0..15) is read row-major from the image: rows 0..7 hold the first half, then the second half is
         // written over them (store_b) and rows 8..15 read the same addresses
         auto store_b = [&]() __attribute__((always_inline)) {
 #pragma unroll
             for (int t = 0; t < 8; ++t) *reinterpret_cast<int4*>(&smp[K ^ (4 * t)]) = Bv[t];
         };
-        auto rice_prep = [&](auto first_tag, int j, RowPrep& R) __attribute__((always_inline)) {
-            constexpr bool FIRST = decltype(first_tag)::value;  // row 0: warm-up samples carry no code
-            const uint32_t gb = (uint32_t)(kRow * j + 4 * lane);
-            const int4 rv = *reinterpret_cast<const int4*>(&smp[rowbase + 256 * (j & 7)]);
-            const int rs[4] = {rv.x, rv.y, rv.z, rv.w};
-            const uint32_t pidx = gb >> l2ps;
-            R.k = kpar[pidx];
-            // partition 0 opens at sample `order`, the others at multiples of the partition size (>= 64)
-            const uint32_t pstart = (pidx == 0u) ? (uint32_t)order : (pidx << l2ps);
-            R.newp = FIRST ? (gb <= pstart && pstart < gb + 4u) : ((gb & (ps - 1u)) == 0u);
-            uint32_t len = 0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint32_t u = (uint32_t)rs[e];  // (folded where the residual was computed)
-                uint32_t q = u >> R.k;
-                if constexpr (FIRST) {
-                    const uint32_t gi = gb + (uint32_t)e;
-                    const bool valid = gi >= (uint32_t)order;
-                    q += (gi == pstart) ? (uint32_t)plen : 0u;
-                    R.u[e] = valid ? u : 0u;
-                    R.q[e] = valid ? q : 0xffffffffu;  // marks "no code"
-                    len += valid ? (q + R.k + 1u) : 0u;
-                } else {
-                    if (e == 0) q += R.newp ? (uint32_t)plen : 0u;
-                    R.u[e] = u;
-                    R.q[e] = q;
-                    len += q;
-                }
-            }
-            R.lane_len = FIRST ? len : (len + 4u * (R.k + 1u));
-            R.incl = wave_incl_scan_u32(R.lane_len);
-            R.total = (uint32_t)__builtin_amdgcn_readlane((int)R.incl, 63);
-        };
-        auto rice_put = [&](auto first_tag, const RowPrep& R) __attribute__((always_inline)) {
-            constexpr bool FIRST = decltype(first_tag)::value;
-            const uint32_t k = R.k, kp1 = k + 1u;
-            const uint32_t onek = 1u << k, mask = onek - 1u;
-            const uint32_t p0 = pos + R.incl - R.lane_len;
-            uint32_t p = p0;
-            if constexpr (FIRST) {
-                const uint32_t gb = (uint32_t)(4 * lane);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool valid = R.q[e] != 0xffffffffu;
-                    if (valid) {
-                        const uint32_t pidx = gb >> l2ps;
-                        if (gb + (uint32_t)e == ((pidx == 0u) ? (uint32_t)order : (pidx << l2ps))) put_bits(p, k, (uint32_t)plen);
-                        put_bits(p + R.q[e], onek | (R.u[e] & mask), kp1);
-                        p += R.q[e] + kp1;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    put_bits(p + R.q[e], onek | (R.u[e] & mask), kp1);
-                    p += R.q[e] + kp1;
-                }
-                if (R.newp) put_bits(p0, k, (uint32_t)plen);
-            }
-        };
-#if FA_F_ROW8
-        // Rows of 512 samples, 8 consecutive samples per lane (two 16-byte units of one chunk): the per-row work -- the
-        // scan of the lane lengths, the parameter lookup, the flush test -- is paid 8 times per frame instead of 16.
+        // Rows of 512 samples, 8 consecutive samples per lane_w (two 16-byte units of one chunk): the per-row work -- the
+        // scan of the lane_w lengths, the parameter lookup, the flush test -- is paid 8 times per frame instead of 16.
         // (The 12288-bit cap of the specification stays a property of 256-sample rows; the sizing pass checked it.)
         {
             const int cb = (ln_ >> 2) + 1;
             const int r8a = 32 * cb + 4 * ((2 * (ln_ & 3)) ^ (cb & 7)), r8b = 32 * cb + 4 * ((2 * (ln_ & 3) + 1) ^ (cb & 7));
             auto row8 = [&](auto first_tag, int j) __attribute__((always_inline)) {
                 constexpr bool FIRST = decltype(first_tag)::value;  // row 0: warm-up samples carry no code
-                const uint32_t gb = (uint32_t)(512 * j + 8 * lane);
+                const uint32_t gb = (uint32_t)(512 * j + 8 * lane_w);
                 const int4 va = *reinterpret_cast<const int4*>(&smp[r8a + 512 * (j & 3)]);
                 const int4 vb = *reinterpret_cast<const int4*>(&smp[r8b + 512 * (j & 3)]);
                 const uint32_t us[8] = {(uint32_t)va.x, (uint32_t)va.y, (uint32_t)va.z, (uint32_t)va.w,
@@ -1381,6 +1427,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
                 const uint32_t lane_len = FIRST ? len : (len + 8u * kp1);
                 const uint32_t incl = wave_incl_scan_u32(lane_len);
                 const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+#ifdef FA_STAMPS
+                const unsigned long long tf0_ = fa_memtime();
+#endif
+                flush_blocks(total, false);
+#ifdef FA_STAMPS
+                st_[15] += fa_memtime() - tf0_;  // (part of "rows": the flush calls)
+#endif
                 const uint32_t onek = 1u << k, mask = onek - 1u;
                 const uint32_t p0 = pos + incl - lane_len;
                 uint32_t p = p0;
@@ -1401,13 +1454,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
                     if (newp) put_bits(p0, k, (uint32_t)plen);
                 }
                 pos += total;
-#ifdef FA_STAMPS
-                const unsigned long long tf0_ = fa_memtime();
-#endif
-                flush_blocks();
-#ifdef FA_STAMPS
-                st_[15] += fa_memtime() - tf0_;  // (part of "rows": the flush calls)
-#endif
             };
             row8(std::true_type{}, 0);
 #pragma unroll 1
@@ -1416,46 +1462,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
                 row8(std::false_type{}, j);
             }
         }
-#else
-        {
-            RowPrep r0;
-            rice_prep(std::true_type{}, 0, r0);
-            rice_put(std::true_type{}, r0);
-            pos += r0.total;
-            flush_blocks();
-        }
-        {
-            constexpr int kLast = 15;
-            RowPrep ra, rb;
-            rice_prep(std::false_type{}, 1, ra);
-#pragma unroll 1
-            for (int j = 1; j <= kLast; j += 2) {
-                if (j == 7) store_b();  // rows 0..7 have been read: the second half takes their place
-                rice_prep(std::false_type{}, j < kLast ? j + 1 : kLast, rb);
-                rice_put(std::false_type{}, ra);
-                pos += ra.total;
-                flush_blocks();
-                if (j == kLast) break;
-                rice_prep(std::false_type{}, j + 2 <= kLast ? j + 2 : kLast, ra);
-                rice_put(std::false_type{}, rb);
-                pos += rb.total;
-                flush_blocks();
-            }
-        }
-#endif
     }
 
     FA_STAMP(11);
     // ---- tail: byte align, CRC-16, final words -----------------------------------------------------------
+    flush_blocks(0u, true);  // the offset is resolved (waiting if need be), parked blocks and every complete block go out
     if (!have_dst) lb_resolve();
     FA_STAMP(13);
     {
         // words not flushed yet: [64 * blocks_flushed, nwords); the CRC covers bytes [0, L)
         const uint32_t nwords = (total_bytes + 3u) >> 2;
-        uint32_t last_end = 256u * blocks_flushed - 256u + 4u * (uint32_t)lane + 4u;  // end of this lane's last folded word (if any block was flushed)
+        uint32_t last_end = 256u * blocks_flushed - 256u + 4u * (uint32_t)lane_w + 4u;  // end of this lane_w's last folded word (if any block was flushed)
         bool any = blocks_flushed > 0;
         for (uint32_t w0 = blocks_flushed * 64; w0 < nwords; w0 += 64) {
-            const uint32_t wl = w0 + lane;
+            const uint32_t wl = w0 + lane_w;
             if (4u * wl < L) {
                 uint32_t wv = ring[wl & kFRingMask];
                 if ((wl & kFRingMask) == 0) wv |= ring[kFRingWords];
@@ -1464,7 +1484,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
                 any = true;
             }
         }
-        // lane states -> CRC: state * x^(8 (L - last_end) - 2016); xpow[i] = x^(8 (i - 255))
+        // lane_w states -> CRC: state * x^(8 (L - last_end) - 2016); xpow[i] = x^(8 (i - 255))
         uint32_t contrib = 0;
         if (any) {
             const int after = (int)L - (int)last_end;  // -3 .. 511
@@ -1477,13 +1497,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
         contrib ^= (uint32_t)xchg_i32<4>((int)contrib);
         const uint32_t crc = ((uint32_t)__builtin_amdgcn_readlane((int)contrib, 0) ^ (uint32_t)__builtin_amdgcn_readlane((int)contrib, 32)) & 0xFFFFu;
         lds_fence();
-        if (lane == 0) put_bits(8u * L, crc, 16);
+        if (lane_w == 0) put_bits(8u * L, crc, 16);
         lds_fence();
         if (!dropped) {
             // the remaining words, and one word of zeros after them: the aligned dword that holds the frame's last
             // (up to 3) bytes starts in the last ring word
             for (uint32_t w0 = blocks_flushed * 64; w0 <= nwords; w0 += 64) {
-                const uint32_t wl = w0 + lane;
+                const uint32_t wl = w0 + lane_w;
                 uint32_t wv = 0;
                 if (wl < nwords) {
                     wv = ring[wl & kFRingMask];
@@ -1495,7 +1515,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
     }
     FA_STAMP(12);
 #ifdef FA_STAMPS
-    if (lane == 0 && a.stamps && (blockIdx.x % 61u) == 0) {  // per XCD: frames, offset wait, lifetime (slots 32 + 4 x)
+    if (lane_w == 0 && a.stamps && (blockIdx.x % 61u) == 0) {  // per XCD: frames, offset wait, lifetime (slots 32 + 4 x)
         uint32_t xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         xcc &= 7u;

@@ -200,6 +200,24 @@ __device__ __forceinline__ double wave_sum_butterfly(double v) {
     v = v + xchg_f64<4>(v);
     return readlane_f64(v, 0) + readlane_f64(v, 32);
 }
+// N sums at once, step by step: every exchange of a step is issued before the first add that needs one, so the N
+// chains overlap (one LDS round trip for all the swizzles of the last step) instead of running one after the other.
+// Same order of additions per value as wave_sum_butterfly: bit-identical results.
+template <int N>
+__device__ __forceinline__ void wave_sum_butterfly_n(double (&v)[N]) {
+    double o[N];
+#define FA_BF_STEP(S)                                          \
+    _Pragma("unroll") for (int i = 0; i < N; ++i) o[i] = xchg_f64<S>(v[i]); \
+    _Pragma("unroll") for (int i = 0; i < N; ++i) v[i] = v[i] + o[i];
+    FA_BF_STEP(0)
+    FA_BF_STEP(1)
+    FA_BF_STEP(2)
+    FA_BF_STEP(3)
+    FA_BF_STEP(4)
+#undef FA_BF_STEP
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = readlane_f64(v[i], 0) + readlane_f64(v[i], 32);
+}
 __device__ __forceinline__ double wave_max_f64(double v) {
     double o;
     o = xchg_f64<0>(v); v = (o > v) ? o : v;
