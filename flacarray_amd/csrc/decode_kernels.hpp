@@ -533,6 +533,11 @@ __device__ __forceinline__ void static_for(F&& f) {
 #ifndef FA_TILE_W
 #define FA_TILE_W 32
 #endif
+#ifndef FA_K7_SPEC
+#define FA_K7_SPEC 0  // experiment (r04, profiles/r04_k7_notes.md): the window's ring words stay in registers and the one word a
+                      // sample can newly need is requested a sample ahead -- the LDS round trip leaves the loop-carried chain,
+                      // two LDS reads per sample go, five vector instructions come: 13 % SLOWER (4.07 against 3.59 ms)
+#endif
 #ifndef FA_K7_SEED
 #define FA_K7_SEED 0
 #endif
@@ -623,6 +628,12 @@ __device__ __forceinline__ void ring_words(uint32_t lane4, uint32_t bitpos, uint
     asm("v_add_lshl_u32 %0, %2, -1, 3\n\tv_and_or_b32 %1, %0, %3, %4" : "=&v"(t), "=v"(ad) : "v"(bitpos), "s"(kRingAddrMask), "v"(lane4));
     const lds_u32* p = (const lds_u32*)(uintptr_t)ad;
     w0 = p[0]; w1 = p[kLaneStride]; w2 = p[2 * kLaneStride];
+}
+// the ring word behind the three that ring_words returns for `bitpos` (its own wrap: no mirror word needed)
+__device__ __forceinline__ uint32_t ring_word3(uint32_t lane4, uint32_t bitpos, uint32_t k95) {
+    uint32_t t, ad;
+    asm("v_add_lshl_u32 %0, %2, %5, 3\n\tv_and_or_b32 %1, %0, %3, %4" : "=&v"(t), "=v"(ad) : "v"(bitpos), "s"(kRingAddrMask), "v"(lane4), "s"(k95));
+    return *(const lds_u32*)(uintptr_t)ad;
 }
 // bits [bitpos, bitpos+32) -> A and [bitpos+32, bitpos+64) -> B
 __device__ __forceinline__ void ring_window(const uint32_t* ring, uint32_t bitpos, uint32_t& A, uint32_t& B) {
@@ -1073,6 +1084,14 @@ __global__ __launch_bounds__(64) FA_K7_WAVES_ATTR void decode_frames_kernel(Deco
                 }
                 ring_words(lane4, bitpos, pw0, pw1, pw2);
             }
+#if FA_K7_SPEC
+            // The three ring words of the window stay in registers from sample to sample: a fast-path code is at most 32 bits
+            // long, so the next window starts in the same word or in the next one, and the only word it can newly need --
+            // the one behind the three -- is requested HERE, from the position the sample starts at.  The LDS round trip
+            // is then off the loop-carried chain (position -> address -> LDS -> window -> code length -> position): the
+            // chain closes with a compare and three selects.
+            const uint32_t pw3 = ring_word3(lane4, bitpos, 95u);
+#endif
             // window from the words prefetched at the end of the previous sample
             const uint32_t sh = (~(bitpos - 1)) & 31;  // 32 - off'
             const uint32_t A = __builtin_amdgcn_alignbit(pw0, pw1, sh);
@@ -1122,9 +1141,24 @@ __global__ __launch_bounds__(64) FA_K7_WAVES_ATTR void decode_frames_kernel(Deco
                         }
                     }
                 }
+#if FA_K7_SPEC
+                // (some lane left the fast path: its position may have moved by any amount -- every lane reads its window again)
+                bitpos = nbp;
+                ring_words(lane4, bitpos, pw0, pw1, pw2);
+#endif
             }
+#if FA_K7_SPEC
+            {
+                const bool cross = (((nbp - 1u) ^ (bitpos - 1u)) >> 5) != 0u;  // (a lane re-read in the rare branch has bitpos == nbp)
+                pw0 = cross ? pw1 : pw0;
+                pw1 = cross ? pw2 : pw1;
+                pw2 = cross ? pw3 : pw2;
+                bitpos = nbp;
+            }
+#else
             bitpos = nbp;
             ring_words(lane4, bitpos, pw0, pw1, pw2);  // LDS latency hides behind the prediction below
+#endif
             if constexpr (PART) pleft--;
             // every term is an exact integer in double, so the order is free: the newest sample enters last and the
             // loop-carried chain is one fma + floor + add
