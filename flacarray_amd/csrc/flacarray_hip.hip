@@ -372,7 +372,11 @@ bool run_verify_beside_begin(hipStream_t st) {
         hipStream_t vs = nullptr;
         int least = 0, greatest = 0;  // (numerically: least priority = the larger number)
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (hipStreamCreateWithPriority(&vs, hipStreamNonBlocking, least) == hipSuccess) {
+        const char* pe = std::getenv("FLACARRAY_HIP_VERIFY_PRIO");  // experiment: "high" / "normal" instead of the lowest priority
+        int prio = least;
+        if (pe && pe[0] == 'h') prio = greatest;
+        else if (pe && pe[0] == 'n') prio = (least + greatest) / 2;
+        if (hipStreamCreateWithPriority(&vs, hipStreamNonBlocking, prio) == hipSuccess) {
             if (hipEventCreateWithFlags(&ds->verify_ev[0], hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&ds->verify_ev[1], hipEventDisableTiming) == hipSuccess) {
                 ds->verify_stream = vs;

@@ -38,35 +38,42 @@ __global__ __launch_bounds__(256) void verify_crc16_kernel(DecodeArgs a, const u
     bool any = false;
     // Eight blocks of 256 bytes per trip: the eight loads of a lane are in flight together and the (serial, LDS-bound)
     // folds follow -- one load per trip made the kernel wait for memory 37 times per frame (3.8 ms at cfg 2; K7 itself
-    // takes 7).  Words past L are zeros that are not folded.
+    // takes 7).  A trip whose 2048 bytes lie inside the frame's CRC range and inside the blob (wave-uniform test) runs
+    // without per-word masks or address arithmetic (one address, immediate offsets: the kernel must stay within 48 registers,
+    // what a SIMD has left beside two waves of K7); the frame's last bytes go word by word.
     constexpr int kBatch = 8;
-    for (uint32_t o0 = 4u * (uint32_t)lane; o0 < L; o0 += 256u * kBatch) {
+    const uint32_t Lin = (uint32_t)(((int64_t)L < a.blob_bytes - start ? (int64_t)L : a.blob_bytes - start) & ~(int64_t)3);  // whole words inside both
+    uint32_t base = 0;
+    for (; base + 256u * kBatch <= Lin; base += 256u * kBatch) {
+        const uint8_t* q = p + base + 4u * (uint32_t)lane;
         uint32_t raw[kBatch];
 #pragma unroll
-        for (int k = 0; k < kBatch; ++k) {
-            const uint32_t o = o0 + 256u * (uint32_t)k;
-            raw[k] = 0;
-            if (o < L) {
-                if (start + o + 4 <= a.blob_bytes) {
-                    __builtin_memcpy(&raw[k], p + o, 4);  // (any byte alignment)
-                } else {  // the last bytes of the blob: byte by byte, in memory order
-                    for (uint32_t b = 0; b < 4 && start + o + b < a.blob_bytes; ++b) raw[k] |= (uint32_t)p[o + b] << (8 * b);
-                }
-            }
-        }
+        for (int k = 0; k < kBatch; ++k) __builtin_memcpy(&raw[k], q + 256 * k, 4);  // (any byte alignment)
 #pragma unroll
         for (int k = 0; k < kBatch; ++k) {
-            const uint32_t o = o0 + 256u * (uint32_t)k;
-            if (o < L) {
-                uint32_t w = __builtin_bswap32(raw[k]);
-                if (o + 4u > L) w &= ~0u << (8u * (4u - (L - o)));  // bytes at and after L (the CRC itself) do not count
-                w ^= crc_t << 16;
-                crc_t = (uint32_t)crc_s[w >> 24] ^ (uint32_t)crc_s[256 + ((w >> 16) & 255u)] ^ (uint32_t)crc_s[512 + ((w >> 8) & 255u)] ^
-                        (uint32_t)crc_s[768 + (w & 255u)];
-                last_end = o + 4u;
-                any = true;
-            }
+            const uint32_t w = __builtin_bswap32(raw[k]) ^ (crc_t << 16);
+            crc_t = (uint32_t)crc_s[w >> 24] ^ (uint32_t)crc_s[256 + ((w >> 16) & 255u)] ^ (uint32_t)crc_s[512 + ((w >> 8) & 255u)] ^
+                    (uint32_t)crc_s[768 + (w & 255u)];
         }
+        last_end = base + 256u * (kBatch - 1) + 4u * (uint32_t)lane + 4u;
+        any = true;
+    }
+    for (uint32_t o = base + 4u * (uint32_t)lane; o < L; o += 256u) {
+        uint32_t w;
+        if (start + o + 4 <= a.blob_bytes) {
+            uint32_t raw;
+            __builtin_memcpy(&raw, p + o, 4);
+            w = __builtin_bswap32(raw);
+        } else {  // the last bytes of the blob: byte by byte
+            w = 0;
+            for (uint32_t b2 = 0; b2 < 4 && start + o + b2 < a.blob_bytes; ++b2) w |= (uint32_t)p[o + b2] << (24 - 8 * b2);
+        }
+        if (o + 4u > L) w &= ~0u << (8u * (4u - (L - o)));  // bytes at and after L (the CRC itself) do not count
+        w ^= crc_t << 16;
+        crc_t = (uint32_t)crc_s[w >> 24] ^ (uint32_t)crc_s[256 + ((w >> 16) & 255u)] ^ (uint32_t)crc_s[512 + ((w >> 8) & 255u)] ^
+                (uint32_t)crc_s[768 + (w & 255u)];
+        last_end = o + 4u;
+        any = true;
     }
     uint32_t contrib = 0;
     if (any) contrib = crc16_mulmod((uint16_t)crc_t, crc_tab[kFCrcSlice + ((int)L - (int)last_end) + 3]);

@@ -31,6 +31,6 @@ def run(verify, reps=6):
 
 print("channels", n_ch)
 print("decode, no check        %.3f ms" % run(False))
-print("decode + K9 beside K7   %.3f ms" % run(True))
+print("decode + K9 beside K7   %.3f ms  (side stream priority: %s)" % (run(True), os.environ.get("FLACARRAY_HIP_VERIFY_PRIO", "lowest")))
 os.environ["FLACARRAY_HIP_VERIFY_AFTER"] = "1"
 print("decode + K9 after K7    %.3f ms" % run(True))
