@@ -62,12 +62,6 @@ constexpr int kFCrcXpow = 520;                                  // x^(8 (i - 255
 #ifndef FA_F_BFLY_N
 #define FA_F_BFLY_N 1  // the nine lag sums step by step side by side (one LDS round trip for all swizzles) instead of one after the other
 #endif
-#ifndef FA_F_SHLEV
-#define FA_F_SHLEV 0  // experiment (r04): one wave of the workgroup runs the Levinson-Durbin phase of all four frames side by side:
-                      // 430 vector instructions per frame fewer (7 %), two workgroup barriers more -- 2.5 % SLOWER (7.26 against
-                      // 7.08 ms at 2048 channels, profiles/r04_k3f_diet.md): the three waves that wait are missed more than
-                      // the instructions
-#endif
 #ifndef FA_F_PARKN
 #define FA_F_PARKN 32  // blocks that can wait in registers (an array of at most 32 registers is indexed in place, s_set_gpr_idx)
 #endif
@@ -316,24 +310,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
     __shared__ __attribute__((aligned(16))) int32_t lds_all[kFWaves * kFWaveWords];
     __shared__ __attribute__((aligned(16))) uint16_t crc_s[kFCrcSlice];
     __shared__ uint32_t ticket_s;
-#if FA_F_SHLEV
-    // hand-over of the workgroup's four Levinson-Durbin problems to one wave (see "Levinson-Durbin" below)
-    __shared__ double lev_in[kFWaves][MLO + 1];
-    __shared__ int lev_bps[kFWaves];
-    __shared__ int lev_out[kFWaves][MLO + 4];
-    __shared__ uint32_t lev_alive;
-#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < kFCrcSlice / 2; i += 256) reinterpret_cast<uint32_t*>(crc_s)[i] = reinterpret_cast<const uint32_t*>(a.crc_tab)[i];
-    if (tid == 0) {
-        ticket_s = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#if FA_F_SHLEV
-        lev_alive = 0;
-#endif
-    }
+    if (tid == 0) ticket_s = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     // (the ticket comes out of LDS, i.e. in a vector register: say that it is wave-uniform, so that the frame number, the
     // stream, the source pointer and everything else derived from it live in scalar registers)
@@ -470,12 +452,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
         return h;
     };
 
-    uint64_t best_bits = verbatim_bits;
-    bool need_lpc = false;  // the lag sums are in and not all zero: Levinson-Durbin and the LPC candidate follow
-    double autoc[MLO + 1];
     if (__builtin_expect(is_const, 0)) {
         type = 0;
     } else {
+        uint64_t best_bits = verbatim_bits;
         // ---- P2: fixed predictors 0..4, lane partial sums over A_l then B_l -------------------------------
         double tot0 = 0.0, tot1 = 0.0, tot2 = 0.0, tot3 = 0.0, tot4 = 0.0;
         double mx0 = 0.0, mx1 = 0.0, mx2 = 0.0, mx3 = 0.0, mx4 = 0.0;
@@ -760,6 +740,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
                 est_fix = 8 + (uint64_t)wasted + (uint64_t)fo * (uint64_t)bps + (uint64_t)fs.best;
                 apply_fixed();
             }
+            double autoc[MLO + 1];
 #if FA_F_BFLY_N
 #pragma unroll
             for (int j = 0; j <= MLO; ++j) autoc[j] = acc[j];
@@ -768,130 +749,59 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MLO > 8 ? 2
 #pragma unroll
             for (int j = 0; j <= MLO; ++j) autoc[j] = wave_sum_butterfly(acc[j]);
 #endif
-            need_lpc = (autoc[0] != 0.0);
-        }
-    }
 
-    FA_STAMP(5);
-    // ---- Levinson-Durbin, order choice, coefficient quantisation ------------------------------------------
-    // A serial computation on nine numbers: run by every wave for itself (the shipped form) it keeps one lane busy for ~610
-    // vector instructions, a tenth of the kernel's instruction stream.  With FA_F_SHLEV the four waves of a workgroup hand
-    // their lag sums to ONE of them, which runs the four problems side by side -- lane group f (16 lanes) works on frame f of
-    // the workgroup, same instructions, same arithmetic -- and hands back order, precision, shift and coefficients: two
-    // workgroup barriers (a wave that has left the kernel is not waited for: s_barrier counts live waves).  Bit-identical,
-    // measured slower (see the flag), kept as the record.
-    const int mlo_arg = a.max_lpc_order;
-    int lpc_ok = 0, lo = 0, prec = a.precision, sh = 0;
-    int32_t qreg[MLO];
-#pragma unroll
-    for (int j = 0; j < MLO; ++j) qreg[j] = 0;
-    {
-        constexpr int kGrp = 16;  // lanes per frame in the worker wave (MLO <= 12 orders evaluated side by side)
-#if FA_F_SHLEV
-        if (lane == 0) {
-#pragma unroll
-            for (int j = 0; j <= MLO; ++j) lev_in[wave][j] = autoc[j];
-            lev_bps[wave] = need_lpc ? bps : -1;
-            atomicOr(&lev_alive, 1u << wave);
-        }
-        __syncthreads();
-        const int worker = __builtin_amdgcn_readfirstlane(__ffs((int)lev_alive) - 1);
-        if (wave == worker) {
-            const int fr = lane / kGrp, sub = lane % kGrp;  // frame of the workgroup, lane within its group
-            uint32_t* const wscr = scr + 256 * fr;          // 1 KB of this wave's idle bit ring per frame
-            double ac[MLO + 1];
-#pragma unroll
-            for (int j = 0; j <= MLO; ++j) ac[j] = lev_in[fr][j];
-            const int fbps = lev_bps[fr];
-#else
-        if (need_lpc) {
-            const int fr = 0, sub = lane;
-            uint32_t* const wscr = scr;
-            double ac[MLO + 1];
-#pragma unroll
-            for (int j = 0; j <= MLO; ++j) ac[j] = autoc[j];
-            const int fbps = bps;
-#endif
-            (void)fr;
-            float* coef = reinterpret_cast<float*>(wscr);         // MLO*MLO floats
-            double* err = reinterpret_cast<double*>(wscr + 160);  // MLO doubles
-            int* meta = reinterpret_cast<int*>(wscr + 220);       // usable order
-            double* mbv = reinterpret_cast<double*>(wscr + 224);  // bits estimate of every order
-            if (sub == 0) meta[0] = levinson<MLO>(ac, mlo_arg, coef, err);
-            lds_fence();
-            const int usable = meta[0];
-            int wprec = a.precision;
-            int wlo;
-            {
-                double mybits = 1e300;
-                if (sub < usable) {
-                    const double e = err[sub];
-                    const double error_scale = a.escale_full;
-                    double bpsv;
-                    if (e > 0.0) {
-                        bpsv = 0.5 * det_log2(error_scale * e);
-                        if (!(bpsv >= 0.0)) bpsv = 0.0;
-                    } else if (e < 0.0) {
-                        bpsv = 1e32;
-                    } else {
-                        bpsv = 0.0;
-                    }
-                    mybits = bpsv * (double)(bs - (sub + 1)) + (double)((sub + 1) * (fbps + wprec));
-                }
-                if (sub < MLO) mbv[sub] = mybits;
+            FA_STAMP(5);
+            if (__builtin_expect(autoc[0] != 0.0, 1)) {
+                float* coef = reinterpret_cast<float*>(scr);         // MLO*MLO floats
+                double* err = reinterpret_cast<double*>(scr + 160);  // MLO doubles
+                int* meta = reinterpret_cast<int*>(scr + 220);       // usable order
+                if (lane == 0) meta[0] = levinson<MLO>(autoc, mlo, coef, err);
                 lds_fence();
-                double bestb = 4294967295.0;
-                int bi = 0;
+                const int usable = meta[0];
+                int prec = a.precision;
+                int lo;
+                {
+                    double mybits = 1e300;
+                    if (lane < usable) {
+                        const double e = err[lane];
+                        const double error_scale = a.escale_full;
+                        double bpsv;
+                        if (e > 0.0) {
+                            bpsv = 0.5 * det_log2(error_scale * e);
+                            if (!(bpsv >= 0.0)) bpsv = 0.0;
+                        } else if (e < 0.0) {
+                            bpsv = 1e32;
+                        } else {
+                            bpsv = 0.0;
+                        }
+                        mybits = bpsv * (double)(bs - (lane + 1)) + (double)((lane + 1) * (bps + prec));
+                    }
+                    double bestb = 4294967295.0;
+                    int bi = 0;
 #pragma unroll
-                for (int o = 0; o < MLO; ++o) {
-                    const double b = mbv[o];
-                    if (o < usable && b < bestb) { bestb = b; bi = o; }
+                    for (int o = 0; o < MLO; ++o) {
+                        const double b = readlane_f64(mybits, o);
+                        if (o < usable && b < bestb) { bestb = b; bi = o; }
+                    }
+                    lo = bi + 1;
                 }
-                wlo = bi + 1;
-            }
-            if (fbps <= 17) {
-                const int limp = 32 - fbps - ilog2_u64((uint64_t)wlo);
-                if (wprec > limp) wprec = limp;
-            }
-            int wsh = 0;
-            int32_t wq[MLO];
+                if (bps <= 17) {
+                    const int limp = 32 - bps - ilog2_u64((uint64_t)lo);
+                    if (prec > limp) prec = limp;
+                }
+                int sh = 0;
+                int32_t qreg[MLO];
 #pragma unroll
-            for (int j = 0; j < MLO; ++j) wq[j] = 0;
-            int wok = 0;
-            if (wprec >= 2) wok = (quantize_coefs_t<MLO>(coef + (wlo - 1) * MLO, wlo, wprec, wq, &wsh) == 0) ? 1 : 0;
-#if FA_F_SHLEV
-            if (fbps < 0) wok = 0;  // (a wave without an LPC candidate: whatever its slot held)
-            if (sub == 0) {
-                lev_out[fr][0] = wok; lev_out[fr][1] = wlo; lev_out[fr][2] = wprec; lev_out[fr][3] = wsh;
+                for (int j = 0; j < MLO; ++j) qreg[j] = 0;
+                int ok = 0;
+                if (prec >= 2) ok = (quantize_coefs_t<MLO>(coef + (lo - 1) * MLO, lo, prec, qreg, &sh) == 0) ? 1 : 0;
+                // (wave-uniform values read from LDS: say so, and they live in scalar registers from here to the preamble)
+                ok = __builtin_amdgcn_readfirstlane(ok);
+                sh = __builtin_amdgcn_readfirstlane(sh);
 #pragma unroll
-                for (int j = 0; j < MLO; ++j) lev_out[fr][4 + j] = wq[j];
-            }
-        }
-        __syncthreads();
-        if (need_lpc) {
-            lpc_ok = lev_out[wave][0]; lo = lev_out[wave][1]; prec = lev_out[wave][2]; sh = lev_out[wave][3];
-#pragma unroll
-            for (int j = 0; j < MLO; ++j) qreg[j] = lev_out[wave][4 + j];
-        }
-#else
-            lpc_ok = wok; lo = wlo; prec = wprec; sh = wsh;
-#pragma unroll
-            for (int j = 0; j < MLO; ++j) qreg[j] = wq[j];
-        }
-#endif
-        // (wave-uniform values read from LDS: say so, and they live in scalar registers from here to the preamble)
-        lpc_ok = __builtin_amdgcn_readfirstlane(lpc_ok);
-        lo = __builtin_amdgcn_readfirstlane(lo);
-        prec = __builtin_amdgcn_readfirstlane(prec);
-        sh = __builtin_amdgcn_readfirstlane(sh);
-#pragma unroll
-        for (int j = 0; j < MLO; ++j) qreg[j] = __builtin_amdgcn_readfirstlane(qreg[j]);
-    }
-    {
-        {
-            {
+                for (int j = 0; j < MLO; ++j) qreg[j] = __builtin_amdgcn_readfirstlane(qreg[j]);
                 FA_STAMP(6);
-                if (__builtin_expect(need_lpc && lpc_ok != 0, 1)) {
+                if (__builtin_expect(ok != 0, 1)) {
                     FA_IMAGE_ADDRS;
                     const double scale = bitsd((uint64_t)(1023 - sh) << 52);  // 2^-sh (exact pre-scaling, see K3)
                     double qd[MLO];
