@@ -20,7 +20,8 @@
 //     asks for;
 //   * the requested range is stored with coalesced stores (optionally dequantised, utils.c:350-368).
 //
-// What this kernel does not take (side / mid stereo assignments, blocks above 4096 samples, predictor orders above 12, frames that do
+// What this kernel does not take (mid / side frames and LPC side channels that need their 33rd bit, blocks above 4096 samples,
+// predictor orders above 12, frames that do
 // not fit the image, anything that does not parse) raises a flag and the launch is repeated by K7, which also owns
 // all error reporting.  Results are bit-identical to K7's.
 #pragma once
@@ -86,7 +87,7 @@ __device__ __forceinline__ uint32_t lat_code_len(const uint32_t* img, uint32_t p
     return q + (uint32_t)__clz((int)A) + 1u + k;
 }
 
-constexpr int kLatResPad = 48;  // the predictor loops work in whole blocks of 16 and look one block ahead: room behind the last sample of a 4096 block
+constexpr int kLatResPad = 80;  // the predictor loops work in whole blocks (LPC: 16 and one block of look-ahead; FIXED: 64) behind the last sample of a 4096 block
 
 // The LPC recurrence of one frame -- serial by nature -- with the TAPS spread over the lanes of a row.
 //
@@ -105,6 +106,43 @@ constexpr int kLatResPad = 48;  // the predictor loops work in whole blocks of 1
 // zeros.  The four rows of the wave do the same work on the same data.  (A lone wave issues one vector instruction per
 // ~6 cycles, profiles/r01k_valu_rates.txt: 116 us of an order-8 frame's 182 were the predictor with order + 4
 // instructions per sample on every lane alike.)
+// The FIXED recurrences (RFC 9639 9.2.5) are repeated prefix sums: with e_j the j-th backward difference of the samples,
+// e_order is the residual, e_j[i] = e_j[i - 1] + e_(j+1)[i], e_0 the samples -- `order` passes of a running sum over the
+// block, each started from the difference of the warm-up samples.  A pass takes the block 64 samples at a time: lane l
+// holds sample base + l, an inclusive scan across the wave (DPP, as the encoder's row writer uses), the carry of the tile
+// before it added as a scalar.  Every lane reads and writes only its own positions in every pass, so the passes need no
+// barrier between them.  Wrapping 32-bit arithmetic is exact (every sample fits its 32 bits, and a 33-bit side channel is
+// wanted modulo 2^32 only).  ~10 instructions per 64 samples and pass; the serial form this replaces (all lanes alike,
+// four samples per trip through LDS) took 75-180 cycles per SAMPLE: 130-310 us for a whole FIXED frame, what the high
+// words of an int64 array and quiet, small-valued data are made of.
+__device__ __forceinline__ uint32_t lat_scan_incl_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+__device__ __forceinline__ void lat_restore_fixed(int32_t* res, int order, int hi) {
+    const int lane = threadIdx.x & 63;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};  // warm-up samples, newest first: w[t] = x[order - 1 - t]
+    for (int t = 0; t < order; ++t) w[t] = (uint32_t)res[order - 1 - t];
+    for (int j = order - 1; j >= 0; --j) {
+        // e_j[order - 1]: the j-th backward difference of the warm-up samples
+        uint32_t carry;
+        if (j == 0) carry = w[0];
+        else if (j == 1) carry = w[0] - w[1];
+        else if (j == 2) carry = w[0] - 2u * w[1] + w[2];
+        else carry = w[0] - 3u * w[1] + 3u * w[2] - w[3];
+        for (int base = order; base < hi; base += 64) {  // (the last tile may run past `hi` into values nobody reads)
+            const uint32_t s = lat_scan_incl_u32((uint32_t)res[base + lane]) + carry;
+            res[base + lane] = (int32_t)s;
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)s, 63);
+        }
+    }
+}
+
 template <int K>
 __device__ __forceinline__ void lat_lpc_step(double& acc, double c) {
     double x;
@@ -131,7 +169,7 @@ __device__ __forceinline__ void lat_restore_lpc(int32_t* res, const double* coef
         const double rn = (double)res[base + 16 + m];
         int32_t out = 0;
         auto hand_over = [&](bool mine) __attribute__((always_inline)) {
-            const int32_t t = (int32_t)fa_floor(acc);
+            const int32_t t = (int32_t)fa_floor(acc);  // (v_cvt_i32_f64 saturates: see the side-channel check of the caller)
             out = mine ? t : out;
             acc = mine ? rn : acc;
         };
@@ -158,8 +196,12 @@ struct LatWide {
     const double* gains;
 };
 
-// NCH == 2: frames with two INDEPENDENT channels (what the int64 encoder writes for all but small-valued frames); the
-// side assignments, whose side channel has 33 bits, stay with K7.  F32 then means "float64 output".
+// NCH == 2: frames with two independent channels (what the int64 encoder writes for all but small-valued frames), left /
+// side and side / right (the latter is what it writes for small values of both signs).  A side channel has 33 bits and
+// this decoder keeps 32: the differences are undone modulo 2^32 -- left = side + right and right = left - side are exact
+// in their low 32 bits whatever bit 32 of the side was, and so are CONSTANT, VERBATIM and the FIXED recurrences (integer
+// coefficients); an LPC-coded side channel needs the true values and hands the frame to K7 if one of them leaves int32.
+// mid / side (a shift of a 33-bit sum) stays with K7.  F32 then means "float64 output".
 template <bool F32, int NCH>
 __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInline inl, LatWide wd, int* fallback) {
     __shared__ __attribute__((aligned(16))) uint32_t img[kLatImgWords + kLatPadWords];
@@ -251,7 +293,7 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
     };
 
     // ---- frame header (RFC 9639 9.1), CRC-8 verified ----
-    int bs = 0, fbps = 0;
+    int bs = 0, fbps = 0, assign = 0;
     {
         uint8_t c8 = 0;
         const uint32_t w = get(32);
@@ -260,7 +302,12 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
         if ((w >> 16) != 0xFFF8) bad = true;
         const uint32_t b2 = (w >> 8) & 0xff, b3 = w & 0xff;
         const int bsc = (int)(b2 >> 4), src = (int)(b2 & 15), ch = (int)(b3 >> 4), ssc = (int)((b3 >> 1) & 7);
-        if (ch != NCH - 1 || (b3 & 1)) bad = true;  // (one channel, or two independent ones)
+        if constexpr (NCH == 2) {
+            if ((ch != 1 && ch != 8 && ch != 9) || (b3 & 1)) bad = true;  // independent, left / side, side / right
+            assign = ch;
+        } else {
+            if (ch != 0 || (b3 & 1)) bad = true;
+        }
         const uint32_t u0 = get(8);
         c8 = crc8_byte(c8, (uint8_t)u0);
         int extra = 0;
@@ -320,20 +367,33 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
         while (!bad && get(1) == 0) { if (++z > 32) bad = true; }
         wasted = (int)z + 1;
     }
-    const int bps = fbps - wasted;
-    if (bps <= 0 || bps > 32) bad = true;
+    const int side = (NCH == 2 && ((assign == 8 && chn == 1) || (assign == 9 && chn == 0))) ? 1 : 0;
+    const int bps = fbps + side - wasted;
+    if (bps <= 0 || bps > 32 + side) bad = true;
     if (bad) { give_up(4); return; }
+    // a field of `bps` bits, low 32 bits of its value; `fits` = false when the value needs the 33rd
+    bool fits = true;
+    auto gets_wide = [&](int n) __attribute__((always_inline)) -> int32_t {
+        if (n <= 32) return gets(n);
+        const uint32_t top = get(1), low = get(32);
+        fits = fits && (top == (low >> 31));
+        return (int32_t)low;
+    };
     int order = 0;
     bool is_lpc = false;
     if (tc == 0) {  // CONSTANT
-        const int32_t v = gets(bps);
+        const int32_t v = gets_wide(bps);
         if (bad) { give_up(4); return; }
         for (int i = lo + lane; i < hi; i += 64) res[i] = v;
     } else if (tc == 1) {  // VERBATIM: fixed-width fields, one lane per sample
         if (pos + (uint32_t)bps * (uint32_t)bs > frame_end_bits) { give_up(4); return; }
-        for (int i = lo + lane; i < hi; i += 64) {
-            const uint32_t v = lat_win(img, pos + (uint32_t)i * (uint32_t)bps) >> (32 - bps);
-            res[i] = (int32_t)(v << (32 - bps)) >> (32 - bps);
+        if (bps > 32) {  // a 33-bit side channel: the low 32 bits of every field
+            for (int i = lo + lane; i < hi; i += 64) res[i] = (int32_t)lat_win(img, pos + (uint32_t)i * 33u + 1u);
+        } else {
+            for (int i = lo + lane; i < hi; i += 64) {
+                const uint32_t v = lat_win(img, pos + (uint32_t)i * (uint32_t)bps) >> (32 - bps);
+                res[i] = (int32_t)(v << (32 - bps)) >> (32 - bps);
+            }
         }
         pos += (uint32_t)bps * (uint32_t)bs;
     } else if ((tc >= 8 && tc <= 12) || tc >= 32) {
@@ -341,9 +401,10 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
         else order = tc - 8;
         if (order > bs || order > 12) { give_up(4); return; }  // (orders 13..32 exist in foreign streams: K7 takes them)
         for (int i = 0; i < order; ++i) {
-            const int32_t v = gets(bps);
+            const int32_t v = gets_wide(bps);
             if (lane == 0) res[i] = v;
         }
+        if (tc >= 32 && !fits) { give_up(4); return; }  // an LPC side channel with a 33-bit warm-up sample: K7 (doubles)
         int shift = 0;
         if (is_lpc) {
             const int prec = (int)get(4) + 1;
@@ -565,29 +626,18 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
         if ((FA_LAT_X & 1) != 0) {
         } else if (is_lpc) {
             lat_restore_lpc(res, coef_s, order, hi);
-        } else if (order > 0) {
-            // FIXED: wrapping 32-bit arithmetic is exact here (every sample fits its 32 bits; RFC 9639 9.2.5)
-            uint32_t x1 = order >= 1 ? (uint32_t)res[order - 1] : 0u, x2 = order >= 2 ? (uint32_t)res[order - 2] : 0u;
-            uint32_t x3 = order >= 3 ? (uint32_t)res[order - 3] : 0u, x4 = order >= 4 ? (uint32_t)res[order - 4] : 0u;
-            for (int i = order; i < hi; i += 4) {  // (groups of four: the reads ahead of the chain; may run past `hi`)
-                uint32_t r[4], o[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) r[u] = (uint32_t)res[i + u];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    uint32_t x0;
-                    if (order == 1) x0 = r[u] + x1;
-                    else if (order == 2) x0 = r[u] + 2u * x1 - x2;
-                    else if (order == 3) x0 = r[u] + 3u * x1 - 3u * x2 + x3;
-                    else x0 = r[u] + 4u * x1 - 6u * x2 + 4u * x3 - x4;
-                    x4 = x3; x3 = x2; x2 = x1; x1 = x0;
-                    o[u] = x0;
-                }
-                if (lane == 0) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) res[i + u] = (int32_t)o[u];
-                }
+            if (side) {
+                // A side channel has 33 bits and this decoder keeps 32; an LPC recurrence (unlike the FIXED ones, exact
+                // modulo 2^32) needs the true values.  The recurrence itself runs in exact doubles, only its stores are
+                // 32 bits wide and saturate: a sample at either end of the int32 range means "possibly more than 32
+                // bits" and hands the frame to K7 (a true INT32_MIN / MAX does so too: slower, never wrong).
+                __syncthreads();
+                bool edge = false;
+                for (int i = order + lane; i < hi; i += 64) edge = edge || res[i] == INT32_MAX || res[i] == INT32_MIN;
+                if (__builtin_amdgcn_ballot_w64(edge) != 0) { give_up(4); return; }
             }
+        } else if (order > 0) {
+            lat_restore_fixed(res, order, hi);
         }
     } else {
         give_up(4);
@@ -605,7 +655,10 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
     if constexpr (NCH == 2) {
         // channel 0 is the low word, channel 1 the high word (utils.c:96-123)
         auto wide = [&](int i) __attribute__((always_inline)) -> int64_t {
-            const uint32_t lw = (uint32_t)res_all[0][i] << wasted_lo, hw = (uint32_t)res_all[NCH - 1][i] << wasted_hi;
+            const uint32_t c0 = (uint32_t)res_all[0][i] << wasted_lo, c1 = (uint32_t)res_all[NCH - 1][i] << wasted_hi;
+            // left / side: right = left - side; side / right: left = side + right (modulo 2^32: see the kernel's header)
+            const uint32_t lw = (assign == 9) ? c0 + c1 : c0;
+            const uint32_t hw = (assign == 8) ? c0 - c1 : c1;
             return (int64_t)(((uint64_t)hw << 32) | lw);
         };
         if constexpr (F32) {

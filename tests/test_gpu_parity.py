@@ -1333,3 +1333,52 @@ def test_few_slices_of_streams_with_large_blocks(fa, block):
             for o, s_i, f0, c in zip(offs, ss, first, cnt):
                 assert np.array_equal(flat[o : o + c], x[s_i, f0 : f0 + c]), (k, s_i, f0, c)
     idx.close()
+
+
+@pytest.mark.parametrize("kind", ["noise", "verbatim_mix"])
+def test_many_frames_in_flight_bytes_equal_oracle(fa, oracle, kind):
+    """Byte identity with thousands of frames in flight.  With a handful of streams every frame finds its byte offset
+    waiting; at this size most frames fill their bit ring before the scanner has their offset and take the other path of
+    the single-pass writer -- completed blocks parked in registers, stored once the offset arrives (encode_fused.hpp,
+    flush_blocks) --, and frames longer than ring + park (VERBATIM: 65 blocks) also reach the spin behind it."""
+    import torch
+
+    n_ch, n = 384, 16 * 4096
+    x = sinusoid_noise_i32(n_ch, n, seed=31)
+    if kind == "verbatim_mix":
+        full = full_range_i32((n_ch, n), seed=32)
+        sel = (np.arange(n_ch)[:, None] + np.arange(n // 4096)[None, :]) % 3 == 0  # every third frame incompressible
+        x = np.where(np.repeat(sel, 4096, axis=1), full, x).astype(np.int32)
+    oracle.lib().oracle_set_threads(8)
+    blob_o, st_o, nb_o = oracle.encode_i32(x, 5, use_threads=True)
+    comp, st, nb = fa.encode_flac_device(torch.from_numpy(x).cuda(), level=5)
+    assert np.array_equal(st.cpu().numpy(), st_o) and np.array_equal(nb.cpu().numpy(), nb_o)
+    assert np.array_equal(comp.cpu().numpy(), blob_o)
+    assert torch.equal(fa.decode_flac_device(comp, st, nb, n, verify=True).cpu(), torch.from_numpy(x))
+
+
+def test_side_channel_that_outgrows_32_bits_under_an_lpc_predictor(fa):
+    """A side / right frame whose side channel starts small (33-bit warm-up sample that fits 32 bits) and grows past
+    2^31 under an LPC predictor: the wave-per-frame decoder keeps side channels modulo 2^32, which an LPC recurrence does
+    not survive -- it has to notice (its 32-bit stores saturate) and leave the frame to K7, whose side channels are
+    doubles.  The same frame with a FIXED predictor (exact modulo 2^32) is decoded in place."""
+    import torch
+
+    from tests.golden.make_golden import frame, stream
+
+    n = 64
+    side = [i * (1 << 26) for i in range(n)]          # 0 .. 63 * 2^26 = 4.2e9 > 2^31: needs the 33rd bit from sample 32 on
+    right = [-(v >> 1) for v in side]                 # left = side + right = side - side / 2 stays inside int32
+    left = [a + b for a, b in zip(side, right)]
+    assert max(left) < 2**31 and min(right) >= -(2**31) and max(side) >= 2**31
+    want = np.array([(r << 32) | (l & 0xFFFFFFFF) for l, r in zip(left, right)], dtype=np.int64)
+    vb = {"type": "verbatim"}
+    for sub in ({"type": "lpc", "order": 1, "coefs": [1], "shift": 0, "precision": 2, "porder": 0, "params": [27], "rice2": True},
+                {"type": "fixed", "order": 1, "porder": 0, "params": [27], "rice2": True}):
+        data = stream([frame([side, right], 0, 32, [sub, vb], assignment=9)], n, 32, n, channels=2)
+        blob = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+        st, nb = torch.zeros(1, dtype=torch.int64).cuda(), torch.tensor([len(data)], dtype=torch.int64).cuda()
+        got = fa.decode_flac_device(blob, st, nb, n, is_int64=True)
+        assert np.array_equal(got.cpu().numpy()[0], want), sub["type"]
+        part = fa.decode_flac_device(blob, st, nb, n, 30, 50, is_int64=True)
+        assert np.array_equal(part.cpu().numpy()[0], want[30:50]), sub["type"]
