@@ -317,6 +317,35 @@ def bench_end_to_end(fa, n_ch=512, n_samp=1 << 20, level=5):
     }
 
 
+def bench_cookbook(fa):
+    """The one workload the reference publishes timings for (docs/docs/cookbook.ipynb cells 4-8: hardware not stated,
+    OMP_NUM_THREADS=4): create_fake_data((1000, 100000), float32), FlacArray.from_array(arr, quanta=1e-7) and
+    to_array(), numpy in and numpy out -- PCIe, the NaN scan and the float conversion included, as in the notebook."""
+    from tests.golden import reference_published as P
+
+    arr = P.fake_data((1000, 100000), np.float32)
+    fa.FlacArray.from_array(arr[:8], quanta=1.0e-7).to_array()  # library tables, staging buffers
+    best_c = best_d = None
+    f = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        f = fa.FlacArray.from_array(arr, quanta=1.0e-7)
+        t1 = time.perf_counter()
+        back = f.to_array()
+        t2 = time.perf_counter()
+        best_c = (t1 - t0) if best_c is None else min(best_c, t1 - t0)
+        best_d = (t2 - t1) if best_d is None else min(best_d, t2 - t1)
+    assert float(np.abs(back - arr).max()) <= 0.5e-7 + 4 * float(np.finfo(np.float32).eps) * float(np.abs(arr).max())
+    return {
+        "workload": "create_fake_data((1000, 100000), float32), FlacArray.from_array(quanta=1e-7) / to_array(), numpy <-> numpy",
+        "from_array_s": round(best_c, 4), "to_array_s": round(best_d, 4),
+        "from_array_Msamples_per_s": round(arr.size / best_c / 1e6, 1), "to_array_Msamples_per_s": round(arr.size / best_d / 1e6, 1),
+        "compressed_bytes": int(f.nbytes),
+        "reference_published": {"from_array_use_threads_s": 1.23, "from_array_s": 2.6, "to_array_s": 0.447,
+                                "hardware": "not stated (notebook output, OMP_NUM_THREADS=4)", "source": "docs/docs/cookbook.ipynb cells 5-8"},
+    }
+
+
 def bench_cfg5(torch, fa, comp, st, nb, n_ch, n_samp, x, dev, n_req=10000, reps=5):
     """Configuration 5 on this rank's store: 10 000 scattered (channel, range) slices in one batched launch,
     from tensors resident in HBM."""
@@ -666,6 +695,10 @@ def main():
         torch.cuda.empty_cache()
         L.fa_release_scratch()
         out["end_to_end"] = bench_end_to_end(fa, level=args.level)
+        try:
+            out["cookbook"] = bench_cookbook(fa)
+        except Exception as e:  # (never takes the line down)
+            out["cookbook"] = f"{type(e).__name__}: {e}"[:200]
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(n_samp)

@@ -57,7 +57,8 @@ constexpr int kFCrcXpow = 520;                                  // x^(8 (i - 255
 #define FA_F_WBATCH 4  // groups of 4 samples whose window values are in flight together in the lag loops
 #endif
 #ifndef FA_F_CEIL
-#define FA_F_CEIL 0  // experiment (r02s): one instruction per sample fewer, yet slower in the same-box A/B
+#define FA_F_CEIL 1  // the sample seeds the prediction chain, r = ceil(x - sum): one instruction per sample fewer.  Slower or flat in
+                     // rounds 2-3 (the kernel was not issue bound then); -1.6 % since the wait for the offset is gone (r04o)
 #endif
 #ifndef FA_F_BFLY_N
 #define FA_F_BFLY_N 1  // the nine lag sums step by step side by side (one LDS round trip for all swizzles) instead of one after the other
