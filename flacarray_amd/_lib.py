@@ -45,6 +45,7 @@ SYMBOLS = [
     "fa_decode_indexed",
     "fa_set_decode_verify",
     "fa_encode_f32_host",
+    "fa_encode_f64_host",
     "fa_decode_indexed_host",
     "fa_pinned_alloc",
     "fa_pinned_free",
@@ -136,6 +137,8 @@ def lib():
     L.fa_decode_indexed.restype = cint
     L.fa_encode_f32_host.argtypes = [vp, i64, i64, u32, vp, pi64, vp, ctypes.POINTER(vp), vp, vp]
     L.fa_encode_f32_host.restype = cint
+    L.fa_encode_f64_host.argtypes = [vp, i64, i64, u32, vp, pi64, vp, ctypes.POINTER(vp), vp, vp]
+    L.fa_encode_f64_host.restype = cint
     L.fa_decode_indexed_host.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, cint]
     L.fa_decode_indexed_host.restype = cint
     L.fa_pinned_alloc.argtypes = [i64]

@@ -1,12 +1,13 @@
 """array_compress: dtype dispatch in front of the encoder (reference: src/flacarray/compress.py:12-84).
 
 Same call signature, return tuple and error behaviour as the reference; the work happens in
-`encode_flac` (K3F / K3-K5) on the GPU, for float data after `float_to_int` (K1; fused into the encoder for float32).
+`encode_flac` (K3F / K3-K5) on the GPU; float data is quantised on the device in the same trip (K1: fused into the
+encoder's load for float32, in front of the two-channel encoder for float64) -- `float_to_int`'s integers never cross PCIe.
 """
 import numpy as np
 
-from .libflacarray import encode_flac, encode_flac_f32
-from .utils import _quanta_for, _streams_of, float_to_int, function_timer
+from .libflacarray import encode_flac, encode_flac_f32, encode_flac_f64
+from .utils import _quanta_for, _streams_of, function_timer
 
 _INT_KINDS = (np.dtype(np.int32), np.dtype(np.int64))
 _FLOAT_KINDS = (np.dtype(np.float32), np.dtype(np.float64))
@@ -64,6 +65,7 @@ def array_compress(arr, level=5, quanta=None, precision=None, use_threads=False)
         lead, _, _ = _streams_of(arr)
         q = _quanta_for(arr, lead, stream_quanta, precision)
         return encode_flac_f32(arr, q if q.size else None, level)
-    ints, offsets, gains = float_to_int(arr, quanta=stream_quanta, precision=precision)
-    compressed, starts, nbytes = encode_flac(ints, level, use_threads=use_threads)
-    return (compressed, starts, nbytes, offsets, gains)
+    # float64 the same way: one trip up, quantised and encoded (two channels) on the device, bytes down
+    lead, _, _ = _streams_of(arr)
+    q = _quanta_for(arr, lead, stream_quanta, precision)
+    return encode_flac_f64(arr, q if q.size else None, level)

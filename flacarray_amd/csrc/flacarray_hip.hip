@@ -1638,9 +1638,12 @@ static int64_t host_chunk_streams(int64_t n_stream, size_t bytes_per_stream, int
 
 // data: int32 (nch 1), int64 (nch 2) or float32 (f32: quantised on the device -- fused into the encoder where the
 // geometry allows, utils.c:160-243; quanta may be null; offsets / gains [n_stream] are outputs)
+// f64 (nch == 2): the input is float64 and is quantised to int64 on the device (float64_to_int64, utils.c:245-327) in
+// front of the two-channel encoder; quanta64 may be null; offsets64 / gains64 [n_stream] are outputs.
 static int encode_host(const void* data_v, int nch, int64_t n_stream, int64_t stream_size, uint32_t level, int64_t* n_bytes,
                        int64_t* starts, unsigned char** bytes, bool f32 = false, const float* quanta = nullptr,
-                       float* offsets = nullptr, float* gains = nullptr) {
+                       float* offsets = nullptr, float* gains = nullptr, bool f64 = false, const double* quanta64 = nullptr,
+                       double* offsets64 = nullptr, double* gains64 = nullptr) {
     FA_API_LOCK;
     const double t_enter = host_now();
     if (level > 8) return FA_ERROR_INVALID_LEVEL;        // compress.c:144-146
@@ -1671,16 +1674,19 @@ static int encode_host(const void* data_v, int nch, int64_t n_stream, int64_t st
     const int64_t wsb = (nch == 2) ? fa_encode_workspace_bytes_i64(chunk, stream_size, level)
                                    : fa_encode_single_pass_workspace_bytes(chunk, stream_size, level);  // (the slot path's size when that runs)
     if ((rc = get_scratch(5, (size_t)wsb, &d_ws))) return rc;
-    if ((rc = get_scratch(4, (size_t)chunk * 28 + 1024, &d_aux))) return rc;
+    if ((rc = get_scratch(4, (size_t)chunk * 40 + 1024, &d_aux))) return rc;
     int64_t* d_starts = reinterpret_cast<int64_t*>(d_aux);
     int64_t* d_nb = d_starts + chunk;
     float* d_q = reinterpret_cast<float*>(d_nb + chunk);
     float* d_off = d_q + chunk;
     float* d_gain = d_off + chunk;
+    double* d_q64 = reinterpret_cast<double*>(d_nb + chunk);  // (the float64 form uses the same region: three doubles per stream)
+    double* d_off64 = d_q64 + chunk;
+    double* d_gain64 = d_off64 + chunk;
     const int64_t cap_chunk = (nch == 1) ? fa_encode_capacity_bytes(chunk, stream_size, level)
                                          : chunk * one.nf * (int64_t)kSlotBytes * 2 + chunk * stream_header_bytes(one.nf);
     if ((rc = get_scratch(3, (size_t)cap_chunk + 256, &d_out))) return rc;
-    if (f32 && !fused_f32 && (rc = get_scratch(11, in_b + 256, &d_int))) return rc;
+    if (((f32 && !fused_f32) || f64) && (rc = get_scratch(11, in_b + 256, &d_int))) return rc;
 
     // the blob: worst case reserved (address space only), populated ahead of the copies, trimmed at the end
     const int64_t cap_total = (nch == 1 ? fa_encode_capacity_bytes(n_stream, stream_size, level)
@@ -1740,7 +1746,17 @@ static int encode_host(const void* data_v, int nch, int64_t n_stream, int64_t st
                                        reinterpret_cast<unsigned char*>(d_out), cap_chunk, d_starts, d_nb, &total, nullptr, nullptr);
             if (err) break;
         } else {
-            err = encode_device_begin(reinterpret_cast<const int32_t*>(d_in), nch, ns, stream_size, level, d_ws, wsb, d_starts, d_nb, &total, nullptr, nullptr);
+            const void* src64 = d_in;
+            if (f64) {
+                if (quanta64 && hipMemcpy(d_q64, quanta64 + s0, (size_t)ns * 8, hipMemcpyHostToDevice) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
+                err = fa_float64_to_int64_device(reinterpret_cast<const double*>(d_in), ns, stream_size, quanta64 ? d_q64 : nullptr,
+                                                 reinterpret_cast<int64_t*>(d_int), d_off64, d_gain64, nullptr);
+                if (err) break;
+                if (hipMemcpy(offsets64 + s0, d_off64, (size_t)ns * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+                    hipMemcpy(gains64 + s0, d_gain64, (size_t)ns * 8, hipMemcpyDeviceToHost) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
+                src64 = d_int;
+            }
+            err = encode_device_begin(reinterpret_cast<const int32_t*>(src64), nch, ns, stream_size, level, d_ws, wsb, d_starts, d_nb, &total, nullptr, nullptr);
             if (err) break;
             if (total > cap_chunk) { err = FA_ERROR_ALLOC; break; }
             err = encode_device_finish(nch, ns, stream_size, level, d_ws, d_starts, reinterpret_cast<unsigned char*>(d_out), nullptr);
@@ -1787,6 +1803,12 @@ int fa_encode_f32_host(const float* data, int64_t n_stream, int64_t stream_size,
                        int64_t* starts, unsigned char** bytes, float* offsets, float* gains) {
     if (!offsets || !gains) return FA_ERROR_CONVERT_TYPE;
     return encode_host(data, 1, n_stream, stream_size, level, n_bytes, starts, bytes, true, quanta, offsets, gains);
+}
+
+int fa_encode_f64_host(const double* data, int64_t n_stream, int64_t stream_size, uint32_t level, const double* quanta, int64_t* n_bytes,
+                       int64_t* starts, unsigned char** bytes, double* offsets, double* gains) {
+    if (!offsets || !gains) return FA_ERROR_CONVERT_TYPE;
+    return encode_host(data, 2, n_stream, stream_size, level, n_bytes, starts, bytes, false, nullptr, nullptr, nullptr, true, quanta, offsets, gains);
 }
 
 int encode_i32(int32_t* const data, int64_t n_stream, int64_t stream_size, uint32_t level, int64_t* n_bytes,

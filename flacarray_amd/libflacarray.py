@@ -235,6 +235,43 @@ def encode_flac_f32(data, quanta, level):
             gains.reshape(lead))
 
 
+def encode_flac_f64(data, quanta, level):
+    """float64 array -> (compressed, starts, nbytes, offsets, gains) in one trip over PCIe (fa_encode_f64_host): the
+    float64 samples go up once, are quantised on the device (float64_to_int64, utils.c:245-327) and encoded from there as
+    two-channel streams -- the same integers, offsets, gains and bytes as `float_to_int` followed by `encode_flac`
+    (compress.py:50-84), which moves the array up, the int64 image down, and the int64 image up again."""
+    _lib.require_device()
+    if data.dtype != np.dtype(np.float64):
+        raise ValueError("Only float64 data is supported")
+    if level < 0 or level > 8:
+        raise RuntimeError("FLAC only supports compression levels 0-8")
+    data = np.ascontiguousarray(data)
+    stream_size = data.shape[-1]
+    lead = data.shape[:-1] if data.ndim > 1 else (1,)
+    n_stream = int(np.prod(lead))
+    q = None
+    if quanta is not None:
+        q = np.ascontiguousarray(quanta, dtype=np.float64).reshape(-1)
+        if q.size != n_stream:
+            raise ValueError("quanta must have one value per stream")
+    flat_starts = np.empty(n_stream, dtype=np.int64)
+    flat_nbytes = np.empty(n_stream, dtype=np.int64)
+    offsets = np.empty(n_stream, dtype=np.float64)
+    gains = np.empty(n_stream, dtype=np.float64)
+    n_bytes = ctypes.c_int64(0)
+    raw = ctypes.c_void_p(None)
+    errcode = _lib.lib().fa_encode_f64_host(_ptr(data), n_stream, stream_size, level, _ptr(q) if q is not None else None,
+                                            ctypes.byref(n_bytes), _ptr(flat_starts), ctypes.byref(raw), _ptr(offsets), _ptr(gains))
+    if errcode & _lib.ERROR_NAN_INPUT:
+        raise RuntimeError("Cannot convert data with NaNs to integers")
+    if errcode != 0:
+        raise RuntimeError(f"Encoding failed, return code = {errcode}")
+    flat_nbytes[:-1] = np.diff(flat_starts)
+    flat_nbytes[-1] = n_bytes.value - flat_starts[-1]
+    return (_adopt_malloc(raw.value, n_bytes.value), flat_starts.reshape(lead), flat_nbytes.reshape(lead), offsets.reshape(lead),
+            gains.reshape(lead))
+
+
 def wrap_encode_i32(flatdata, n_stream, stream_size, level):
     """libflacarray.pyx:285-343"""
     return _wrap_encode(_lib.lib().encode_i32, flatdata, n_stream, stream_size, level)

@@ -142,6 +142,13 @@ int fa_encode_f32_device(const float* d_data, int64_t n_stream, int64_t stream_s
 int fa_encode_f32_host(const float* data, int64_t n_stream, int64_t stream_size, uint32_t level, const float* quanta,
                        int64_t* n_bytes, int64_t* starts, unsigned char** bytes, float* offsets, float* gains);
 
+/* The float64 twin: what array_compress does with float64 input -- float64_to_int64 (utils.c:245-327) followed by
+ * encode_i64 (compress.py:50-84) -- in one trip: the float64 samples go up once, are quantised on the device and encoded
+ * from there as two-channel streams; the int64 image never crosses PCIe (the two-call form moves 8 B per sample down and
+ * up again).  quanta may be NULL; offsets / gains [n_stream] are outputs.  FA_ERROR_NAN_INPUT for a NaN. */
+int fa_encode_f64_host(const double* data, int64_t n_stream, int64_t stream_size, uint32_t level, const double* quanta,
+                       int64_t* n_bytes, int64_t* starts, unsigned char** bytes, double* offsets, double* gains);
+
 /* The same three calls for int64 input (two-channel streams); d_info, if given, holds one
  * FrameInfo per SUBFRAME: [ (stream * frames + frame) * 2 + channel ]. */
 int64_t fa_encode_workspace_bytes_i64(int64_t n_stream, int64_t stream_size, uint32_t level);
@@ -259,7 +266,7 @@ const char* fa_version(void);
  * do not / process default, see fa_set_decode_verify); a binding built against
  * another revision must refuse the library instead of calling it with a shifted argument list --
  * flacarray_amd/_lib.py does. */
-#define FA_ABI_VERSION 2
+#define FA_ABI_VERSION 2  /* (new entry points do not raise it: fa_encode_f64_host came with revision 2) */
 int fa_abi_version(void);
 
 #ifdef __cplusplus

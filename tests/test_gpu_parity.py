@@ -1135,6 +1135,24 @@ def test_host_abi_pipeline_many_chunks(fa, oracle, monkeypatch):
         bad = xf.copy()
         bad[3, 17] = np.nan
         fa.array_compress(bad, quanta=1e-3)
+    # float64 in one trip (fa_encode_f64_host) == float_to_int followed by encode_flac (two-channel streams), several chunks
+    from flacarray_amd.libflacarray import encode_flac_f64
+
+    xd = (sinusoid_noise_f32(9, 12000, seed=8).astype(np.float64) * 1.0e3) + np.arange(9)[:, None] * 0.125
+    for q in (None, np.full(9, 2.0**-20) * (1 + np.arange(9) % 3)):
+        monkeypatch.setenv("FLACARRAY_HIP_HOST_CHUNK_BYTES", str(2 * 12000 * 8))
+        got = encode_flac_f64(xd, q, 5)
+        ints, off, gain = fa.float_to_int(xd, quanta=None if q is None else q)
+        c2, s2, n2 = fa.encode_flac(ints, 5)
+        assert np.array_equal(got[0], c2) and np.array_equal(got[1], s2) and np.array_equal(got[2], n2)
+        assert np.array_equal(got[3], off) and np.array_equal(got[4], gain)
+    comp64 = fa.array_compress(xd, precision=9)
+    back = fa.array_decompress(comp64[0], xd.shape[1], comp64[1], comp64[2], stream_offsets=comp64[3], stream_gains=comp64[4], is_int64=True)
+    assert np.all(np.abs(back - xd) <= 0.5 * (np.std(xd, axis=-1, keepdims=True) / 1e9) * (1 + 1e-9) + 4 * np.finfo(np.float64).eps * np.abs(xd).max())
+    with pytest.raises(RuntimeError, match="NaNs"):
+        bad = xd.copy()
+        bad[2, 5] = np.nan
+        fa.array_compress(bad, precision=5)
 
 
 def test_latency_decoder_matches_throughput_decoder(fa, oracle, monkeypatch):
