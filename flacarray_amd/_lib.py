@@ -46,6 +46,8 @@ SYMBOLS = [
     "fa_set_decode_verify",
     "fa_encode_f32_host",
     "fa_encode_f64_host",
+    "fa_decode_f32_host",
+    "fa_decode_f64_host",
     "fa_decode_indexed_host",
     "fa_pinned_alloc",
     "fa_pinned_free",
@@ -139,6 +141,10 @@ def lib():
     L.fa_encode_f32_host.restype = cint
     L.fa_encode_f64_host.argtypes = [vp, i64, i64, u32, vp, pi64, vp, ctypes.POINTER(vp), vp, vp]
     L.fa_encode_f64_host.restype = cint
+    L.fa_decode_f32_host.argtypes = [vp, vp, vp, i64, i64, i64, i64, vp, vp, vp]
+    L.fa_decode_f32_host.restype = cint
+    L.fa_decode_f64_host.argtypes = [vp, vp, vp, i64, i64, i64, i64, vp, vp, vp]
+    L.fa_decode_f64_host.restype = cint
     L.fa_decode_indexed_host.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, cint]
     L.fa_decode_indexed_host.restype = cint
     L.fa_pinned_alloc.argtypes = [i64]

@@ -1885,8 +1885,11 @@ struct ChunkRanges {
     }
 };
 
+// offsets / gains (both or neither; float for one channel, double for two): the int -> float restore (utils.c:329-368) is
+// fused into the decoder's store and `data_v` receives float32 / float64 -- the integers never cross PCIe.
 static int decode_host(const unsigned char* bytes, const int64_t* starts, const int64_t* nbytes, int64_t n_stream,
-                       int64_t stream_size, int64_t first_sample, int64_t last_sample, void* data_v, int nch) {
+                       int64_t stream_size, int64_t first_sample, int64_t last_sample, void* data_v, int nch,
+                       const void* offsets = nullptr, const void* gains = nullptr) {
     FA_API_LOCK;
     const double t_enter = host_now();
     const size_t esz = 4 * (size_t)nch;  // bytes per decoded sample
@@ -1938,7 +1941,7 @@ static int decode_host(const unsigned char* bytes, const int64_t* starts, const 
     }
     void *d_blob2 = nullptr, *d_aux2 = nullptr, *d_out = nullptr;
     const size_t blob_slot = align_up((size_t)max_packed + 256, 256);
-    const size_t aux_slot = align_up((size_t)chunk * 16 + 512, 256);
+    const size_t aux_slot = align_up((size_t)chunk * 32 + 512, 256);  // starts, nbytes, (offsets, gains: up to 8 B each)
     int err = FA_ERROR_NONE;
     if ((err = get_scratch(0, (n_chunks > 1 ? 2 : 1) * blob_slot, &d_blob2))) return err;
     if ((err = get_scratch(4, 2 * aux_slot, &d_aux2))) return err;
@@ -1959,6 +1962,12 @@ static int decode_host(const unsigned char* bytes, const int64_t* starts, const 
         char* da = reinterpret_cast<char*>(d_aux2) + (size_t)slot * aux_slot;
         if (hipMemcpyAsync(da, r.rel.data(), (size_t)ns * 8, hipMemcpyHostToDevice, st) != hipSuccess) return FA_ERROR_DEVICE;
         if (hipMemcpyAsync(da + (size_t)chunk * 8, nbytes + s0, (size_t)ns * 8, hipMemcpyHostToDevice, st) != hipSuccess) return FA_ERROR_DEVICE;
+        if (offsets) {
+            const size_t fsz = (nch == 2) ? 8 : 4;
+            if (hipMemcpyAsync(da + (size_t)chunk * 16, reinterpret_cast<const char*>(offsets) + (size_t)s0 * fsz, (size_t)ns * fsz, hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipMemcpyAsync(da + (size_t)chunk * 24, reinterpret_cast<const char*>(gains) + (size_t)s0 * fsz, (size_t)ns * fsz, hipMemcpyHostToDevice, st) != hipSuccess)
+                return FA_ERROR_DEVICE;
+        }
         return FA_ERROR_NONE;
     };
     Feeder feed;
@@ -1977,14 +1986,18 @@ static int decode_host(const unsigned char* bytes, const int64_t* starts, const 
         const int64_t* d_starts = reinterpret_cast<const int64_t*>(reinterpret_cast<char*>(d_aux2) + (size_t)slot * aux_slot);
         const int64_t* d_nb = d_starts + chunk;
         const int64_t packed = cr[(size_t)c].packed;
+        const char* d_fo = reinterpret_cast<const char*>(d_starts) + (size_t)chunk * 16;  // offsets, gains of the chunk (if any)
+        const char* d_fg = reinterpret_cast<const char*>(d_starts) + (size_t)chunk * 24;
         if (nch == 1)
             err = decode_device_impl(db, packed, d_starts, d_nb, ns, stream_size, first_decode, n_decode, -1, nullptr, nullptr, nullptr, nullptr,
-                                     reinterpret_cast<int32_t*>(d_out), nullptr, nullptr, nullptr, nullptr, 1, nullptr, nullptr, nullptr, nullptr,
-                                     nullptr, false, host_verify);
+                                     offsets ? nullptr : reinterpret_cast<int32_t*>(d_out), offsets ? reinterpret_cast<float*>(d_out) : nullptr,
+                                     offsets ? reinterpret_cast<const float*>(d_fo) : nullptr, offsets ? reinterpret_cast<const float*>(d_fg) : nullptr,
+                                     nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, false, host_verify);
         else
             err = decode_device_impl(db, packed, d_starts, d_nb, ns, stream_size, first_decode, n_decode, -1, nullptr, nullptr, nullptr, nullptr,
-                                     nullptr, nullptr, nullptr, nullptr, nullptr, 2, reinterpret_cast<int64_t*>(d_out), nullptr, nullptr, nullptr,
-                                     nullptr, false, host_verify);
+                                     nullptr, nullptr, nullptr, nullptr, nullptr, 2, offsets ? nullptr : reinterpret_cast<int64_t*>(d_out),
+                                     offsets ? reinterpret_cast<double*>(d_out) : nullptr, offsets ? reinterpret_cast<const double*>(d_fo) : nullptr,
+                                     offsets ? reinterpret_cast<const double*>(d_fg) : nullptr, nullptr, false, host_verify);
         if (n_chunks > 1) feed.done_with(c);  // (the decode call ends with a stream synchronisation: the slot is free)
         if (err) break;
         const double td0 = host_now();
@@ -2008,6 +2021,18 @@ int decode_i64(unsigned char* const bytes, int64_t* const starts, int64_t* const
                int64_t stream_size, int64_t first_sample, int64_t last_sample, int64_t* data, bool use_threads) {
     (void)use_threads;
     return decode_host(bytes, starts, nbytes, n_stream, stream_size, first_sample, last_sample, data, 2);
+}
+
+int fa_decode_f32_host(const unsigned char* bytes, const int64_t* starts, const int64_t* nbytes, int64_t n_stream, int64_t stream_size,
+                       int64_t first_sample, int64_t last_sample, const float* offsets, const float* gains, float* data) {
+    if (!offsets || !gains) return FA_ERROR_CONVERT_TYPE;
+    return decode_host(bytes, starts, nbytes, n_stream, stream_size, first_sample, last_sample, data, 1, offsets, gains);
+}
+
+int fa_decode_f64_host(const unsigned char* bytes, const int64_t* starts, const int64_t* nbytes, int64_t n_stream, int64_t stream_size,
+                       int64_t first_sample, int64_t last_sample, const double* offsets, const double* gains, double* data) {
+    if (!offsets || !gains) return FA_ERROR_CONVERT_TYPE;
+    return decode_host(bytes, starts, nbytes, n_stream, stream_size, first_sample, last_sample, data, 2, offsets, gains);
 }
 
 int float32_to_int32(float const* input, int64_t n_stream, int64_t stream_size, float const* quanta, int32_t* output,

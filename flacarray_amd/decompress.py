@@ -2,12 +2,28 @@
 decoder (reference: src/flacarray/decompress.py:18-205).
 
 Same signatures, return values and error behaviour as the reference; K6/K7 do the decoding on the
-GPU and `int_to_float` (K2) the float restore.
+GPU with the float restore (`int_to_float`, K2) fused into the decoder's store for float data.
 """
 import numpy as np
 
-from .libflacarray import decode_flac
+from .libflacarray import decode_flac, decode_flac_restore
 from .utils import ensure_one_element, function_timer, int_to_float, keep_select, select_keep_indices
+
+
+def _plausible_float_call(compressed, starts, nbytes, stream_size, first, last, offsets, gains):
+    """True when the arguments are what the fused decode + restore takes as they are; anything else goes through
+    decode_flac / int_to_float, whose checks raise the reference's errors (libflacarray.pyx:751-789, utils.py:367-386)."""
+    try:
+        return (
+            isinstance(compressed, np.ndarray) and compressed.dtype == np.uint8 and compressed.ndim == 1 and compressed.flags.c_contiguous
+            and isinstance(starts, np.ndarray) and starts.dtype == np.int64 and starts.flags.c_contiguous
+            and isinstance(nbytes, np.ndarray) and nbytes.dtype == np.int64 and nbytes.shape == starts.shape and nbytes.flags.c_contiguous
+            and stream_size > 0 and isinstance(offsets, np.ndarray) and isinstance(gains, np.ndarray)
+            and offsets.size == starts.size and gains.size == starts.size
+            and (first < 0 or last < 0 or (first < last <= stream_size))
+        )
+    except Exception:  # noqa: BLE001  (odd argument types: the plain path will say what is wrong with them)
+        return False
 
 
 def _single_stream(stream_starts):
@@ -47,12 +63,20 @@ def array_decompress_slice(
             stream_gains = ensure_one_element(stream_gains, ftype)
 
     starts, nbytes, indices = keep_select(keep, stream_starts, stream_nbytes)
-    arr = decode_flac(
-        compressed, starts, nbytes, stream_size, first_sample=first, last_sample=last, use_threads=use_threads,
-        is_int64=is_int64,
-    )
+    arr = None
     if to_float:
-        arr = int_to_float(arr, select_keep_indices(stream_offsets, indices), select_keep_indices(stream_gains, indices))
+        # one trip over PCIe: the restore is fused into the decoder's store, the integers stay on the device
+        sel_off, sel_gain = select_keep_indices(stream_offsets, indices), select_keep_indices(stream_gains, indices)
+        if _plausible_float_call(compressed, starts, nbytes, stream_size, first, last, sel_off, sel_gain):
+            arr = decode_flac_restore(compressed, starts, nbytes, stream_size, sel_off, sel_gain, first_sample=first, last_sample=last,
+                                      is_int64=is_int64)
+    if arr is None:
+        arr = decode_flac(
+            compressed, starts, nbytes, stream_size, first_sample=first, last_sample=last, use_threads=use_threads,
+            is_int64=is_int64,
+        )
+        if to_float:
+            arr = int_to_float(arr, select_keep_indices(stream_offsets, indices), select_keep_indices(stream_gains, indices))
     if single and not no_flatten:
         arr = arr.reshape(-1)
     return (arr, indices)

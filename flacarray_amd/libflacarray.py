@@ -414,6 +414,33 @@ def decode_flac(compressed, starts, nbytes, stream_size, first_sample=-1, last_s
     return flat_output.reshape(output_shape)
 
 
+def decode_flac_restore(compressed, starts, nbytes, stream_size, offsets, gains, first_sample=-1, last_sample=-1, is_int64=False):
+    """`decode_flac` followed by `int_to_float` (decompress.py:107-136) in one trip over PCIe: compressed bytes up, the
+    restore of utils.c:329-368 fused into the decoder's store, float32 / float64 down (fa_decode_f32_host /
+    fa_decode_f64_host) -- the same values, bit for bit, as the two calls.  Shapes as decode_flac; offsets / gains have
+    the shape of `starts`.  Returns None when the library refuses the call (e.g. streams of different block sizes): the
+    caller then takes the two-call path, which knows how to split such a store."""
+    _lib.require_device()
+    n_decode = stream_size if (first_sample < 0 or last_sample < 0) else last_sample - first_sample
+    ftype = np.float64 if is_int64 else np.float32
+    st = np.ascontiguousarray(starts, dtype=np.int64)
+    nb = np.ascontiguousarray(nbytes, dtype=np.int64).reshape(-1)
+    off = np.ascontiguousarray(offsets, dtype=ftype).reshape(-1)
+    gain = np.ascontiguousarray(gains, dtype=ftype).reshape(-1)
+    n_stream = int(st.size)
+    if off.size != n_stream or gain.size != n_stream or n_decode <= 0:
+        return None
+    compressed = np.ascontiguousarray(compressed, dtype=np.uint8)
+    out = np.empty(n_stream * n_decode, dtype=ftype)
+    _advise_huge_pages(out)
+    fn = _lib.lib().fa_decode_f64_host if is_int64 else _lib.lib().fa_decode_f32_host
+    errcode = fn(_ptr(compressed), _ptr(st.reshape(-1)), _ptr(nb), n_stream, int(stream_size), int(first_sample), int(last_sample),
+                 _ptr(off), _ptr(gain), _ptr(out))
+    if errcode != 0:
+        return None
+    return out.reshape(st.shape + (n_decode,))
+
+
 def decode_flac_into(compressed, starts, nbytes, stream_size, out, first_sample=-1, last_sample=-1):
     """`decode_flac` into an array the caller owns: the C boundary takes a caller-allocated output (decode_i32 /
     decode_i64, flacarray.h:249-271; libflacarray.pyx:634 allocates a fresh one per call), and a caller that decodes

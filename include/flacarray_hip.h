@@ -149,6 +149,15 @@ int fa_encode_f32_host(const float* data, int64_t n_stream, int64_t stream_size,
 int fa_encode_f64_host(const double* data, int64_t n_stream, int64_t stream_size, uint32_t level, const double* quanta,
                        int64_t* n_bytes, int64_t* starts, unsigned char** bytes, double* offsets, double* gains);
 
+/* Decode with the int -> float restore fused into the decoder's store: what array_decompress_slice does for float data
+ * (decode_flac, then int_to_float: decompress.py:107-136, utils.c:329-368) in one trip -- compressed bytes up, floats
+ * down; the integers never cross PCIe.  offsets / gains [n_stream] as float_to_int returned them; data is
+ * float32 / float64 [n_stream][n_decode]; sample range and error codes as decode_i32 / decode_i64 (frame CRC-16s checked). */
+int fa_decode_f32_host(const unsigned char* bytes, const int64_t* starts, const int64_t* nbytes, int64_t n_stream, int64_t stream_size,
+                       int64_t first_sample, int64_t last_sample, const float* offsets, const float* gains, float* data);
+int fa_decode_f64_host(const unsigned char* bytes, const int64_t* starts, const int64_t* nbytes, int64_t n_stream, int64_t stream_size,
+                       int64_t first_sample, int64_t last_sample, const double* offsets, const double* gains, double* data);
+
 /* The same three calls for int64 input (two-channel streams); d_info, if given, holds one
  * FrameInfo per SUBFRAME: [ (stream * frames + frame) * 2 + channel ]. */
 int64_t fa_encode_workspace_bytes_i64(int64_t n_stream, int64_t stream_size, uint32_t level);

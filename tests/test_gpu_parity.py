@@ -1153,6 +1153,26 @@ def test_host_abi_pipeline_many_chunks(fa, oracle, monkeypatch):
         bad = xd.copy()
         bad[2, 5] = np.nan
         fa.array_compress(bad, precision=5)
+    # decode + restore in one trip (fa_decode_f32_host / fa_decode_f64_host) == decode_flac followed by int_to_float, bit for
+    # bit: whole streams, a sample range, a scattered subset, several chunks
+    from flacarray_amd.libflacarray import decode_flac_restore
+
+    for arr, is64 in ((xf, False), (xd, True)):
+        monkeypatch.setenv("FLACARRAY_HIP_HOST_CHUNK_BYTES", str(3 * arr.shape[1] * arr.itemsize))
+        comp, st, nb, off, gain = fa.array_compress(arr, quanta=2.0**-14)
+        for first, last in ((-1, -1), (4000, 9001)):
+            ints = fa.decode_flac(comp, st, nb, arr.shape[1], first_sample=first, last_sample=last, is_int64=is64)
+            want = fa.int_to_float(ints, off, gain)
+            got = decode_flac_restore(comp, st, nb, arr.shape[1], off, gain, first_sample=first, last_sample=last, is_int64=is64)
+            assert got is not None and got.dtype == arr.dtype and np.array_equal(got, want)
+        pick = np.array([7, 0, 5])
+        got = decode_flac_restore(comp, st[pick].copy(), nb[pick].copy(), arr.shape[1], off[pick].copy(), gain[pick].copy(), is_int64=is64)
+        assert np.array_equal(got, fa.int_to_float(fa.decode_flac(comp, st[pick].copy(), nb[pick].copy(), arr.shape[1], is_int64=is64), off[pick], gain[pick]))
+        keep = np.zeros(arr.shape[0], dtype=bool)
+        keep[[1, 4]] = True
+        sub, idx = fa.array_decompress_slice(comp, arr.shape[1], st, nb, stream_offsets=off, stream_gains=gain, keep=keep,
+                                             first_stream_sample=100, last_stream_sample=350, is_int64=is64)
+        assert idx == [(1,), (4,)] and np.array_equal(sub, fa.int_to_float(fa.decode_flac(comp, st[keep].copy(), nb[keep].copy(), arr.shape[1], 100, 350, is_int64=is64), off[keep], gain[keep]))
 
 
 def test_latency_decoder_matches_throughput_decoder(fa, oracle, monkeypatch):

@@ -162,7 +162,18 @@ def cpu_backend(monkeypatch, oracle):
     import flacarray_amd.compress as C
     import flacarray_amd.utils as U
 
+    def enc_f64(data, quanta, level):  # the float64 twin
+        lead = data.shape[:-1] if data.ndim > 1 else (1,)
+        flat = np.ascontiguousarray(data).reshape(int(np.prod(lead)), data.shape[-1])
+        ints, off, g = oracle.float64_to_int64(flat, quanta)
+        blob, st, nb = oracle.encode_i64(ints, level)
+        return blob, st.reshape(lead), nb.reshape(lead), off.reshape(lead), g.reshape(lead)
+
+    import flacarray_amd.decompress as D
+
     monkeypatch.setattr(C, "encode_flac_f32", enc_f32)
+    monkeypatch.setattr(C, "encode_flac_f64", enc_f64)
+    monkeypatch.setattr(D, "decode_flac_restore", lambda *a, **k: None)  # (the fused decode + restore: decode, then int_to_float)
     monkeypatch.setattr(libflacarray, "wrap_encode_i32", enc)
     monkeypatch.setattr(libflacarray, "wrap_encode_i32_threaded", enc)
     monkeypatch.setattr(libflacarray, "wrap_decode_i32", dec)

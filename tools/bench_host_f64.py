@@ -24,3 +24,13 @@ for name, fn in (("one trip (array_compress)", lambda: fa.array_compress(x, prec
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     print(f"{name}: {best * 1e3:.1f} ms for {x.nbytes / 1e6:.0f} MB of float64 ({x.size / best / 1e6:.0f} Msamples/s), {out[0].nbytes / x.nbytes:.3f} of the raw size")
+comp, st, nb, off, gain = fa.array_compress(x, precision=10)
+for name, fn in (("one trip (array_decompress)", lambda: fa.array_decompress(comp, n, st, nb, stream_offsets=off, stream_gains=gain, is_int64=True)),
+                 ("two calls (decode_flac + int_to_float)", lambda: fa.int_to_float(fa.decode_flac(comp, st, nb, n, is_int64=True), off, gain))):
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        out = fn()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    print(f"{name}: {best * 1e3:.1f} ms back to {out.nbytes / 1e6:.0f} MB of float64 ({out.size / best / 1e6:.0f} Msamples/s)")
