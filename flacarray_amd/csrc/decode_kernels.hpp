@@ -504,6 +504,7 @@ struct DecodeArgs {
     uint32_t* hibits;   // [n_tasks][2][hib_words] bit 32 of every sample
     int32_t* assign;    // [n_tasks] channel assignment once both subframes are decoded, else -1
     int32_t hib_words;  // ceil(B / 32)
+    int32_t verbatim_done;  // NCH == 2: VERBATIM first subframes (no wasted bits) were decoded by verbatim_channel0_kernel
 };
 
 // ------------------------------------------------------------------------------------------
@@ -896,6 +897,7 @@ __global__ __launch_bounds__(64) FA_K7_WAVES_ATTR void decode_frames_kernel(Deco
 #pragma unroll
     for (int j = 0; j < MO; ++j) { c[j] = 0.0; h[j] = 0.0; }
     int plen = 4, esc = 15, ps = 0, pleft = 0, k = 0, escw = -1;
+    uint32_t kp1 = 1;  // k + 1: the bits a code takes beyond its zeros (0 for a lane that consumes nothing, see below)
     uint32_t hbw = 0;  // NCH == 2: bit 32 (the sign) of the samples of the current tile
 
     if (task_live) {
@@ -972,15 +974,46 @@ __global__ __launch_bounds__(64) FA_K7_WAVES_ATTR void decode_frames_kernel(Deco
             hi = (int)(h2 > l ? h2 : l);
         }
     }
+    // A VERBATIM first subframe (no wasted bits) is a run of fixed-width fields: verbatim_channel0_kernel has decoded it
+    // with a lane per sample.  This lane steps over it -- bs x bps bits -- and sits out the channel; a wave whose 64 frames
+    // all do (the low words of fine-grained float64 data are incompressible: every frame) skips the channel's loop.
+    uint32_t resume_bitpos = 0;
+    bool skipped = false;
+    if constexpr (NCH == 2) {
+        if (chn == 0 && task_live && mode == 1 && wasted == 0 && a.verbatim_done) {
+            skipped = true;
+            resume_bitpos = bitpos + (uint32_t)bps * (uint32_t)bs;
+            mode = 3;
+            lo = hi = 0;
+        }
+    }
     // ---- unify every lane as a "predictive" lane so the sample loop has one code path ----
     //   CONSTANT : order-1 predictor with c0 = 1 on h0 = value, zero-width escape residuals
     //   VERBATIM : no predictor, escape residuals of width bps in one endless partition
     //   idle     : zero-width escapes, nothing stored (empty row range)
-    if (mode == 3) { bs = 0x7fffffff; next_chunk = 0x00400000u; bitpos = 0; order = 0; escw = 0; pleft = 0x7fffffff; ps = 0; }
+    // A lane that consumes no bits in this channel -- CONSTANT subframe, idle lane, subframe decoded elsewhere -- must not
+    // drag the wave into the rare branch at every sample (a zero-width escape fails the fast-path test; the high words of
+    // an int64 array are CONSTANT frames more often than not: 3.3x the instructions per wave, measured).  It becomes a
+    // plain Rice lane with k = 0 and a code that takes ZERO bits beyond its zeros (kp1 = 0), reading a ring column filled
+    // with ones: no zeros, stop bit at once, value 0, position unchanged -- on the fast path.  Its real position is kept
+    // aside and restored (ring re-read) when the channel is over.
+    bool zero_width = false;
+    if (mode == 3) { bs = 0x7fffffff; order = 0; ps = 0; zero_width = true; }
     if (mode == 0) {
 #pragma unroll
         for (int j = 0; j < MO; ++j) { c[j] = 0.0; h[j] = cval; }
-        c[0] = 1.0; scale = 1.0; order = 0; escw = 0; pleft = 0x7fffffff;
+        c[0] = 1.0; scale = 1.0; order = 0;
+        if constexpr (NCH == 2) {
+            if (chn == 0) { resume_bitpos = bitpos; skipped = true; }  // the second subframe starts behind the constant
+        }
+        zero_width = true;
+    }
+    if (zero_width) { next_chunk = 0x00400000u; bitpos = 8; escw = -1; k = 0; kp1 = 0; pleft = 0x7fffffff; }
+    if (__any(zero_width)) {
+        if (zero_width) {
+#pragma unroll 1
+            for (int j = 0; j < kRingW + 2; ++j) ring[j * kLaneStride] = 0xffffffffu;  // (ring words and their two mirror words)
+        }
     }
     if (mode == 1) {
 #pragma unroll
@@ -1055,9 +1088,19 @@ __global__ __launch_bounds__(64) FA_K7_WAVES_ATTR void decode_frames_kernel(Deco
     };
     uint32_t pw0, pw1, pw2;  // ring words of the current bit position
     ring_words(lane4, bitpos, pw0, pw1, pw2);
-    // fast-path key: a plain Rice code of at most 32 bits  <=>  zr < zlim (unsigned; v_ffbh_u32 gives 0xffffffff for an
+    // fast-path key: a plain Rice code of at most kFastBits bits (stop bit inside the window)  <=>  zr < zlim (unsigned; v_ffbh_u32 gives 0xffffffff for an
     // empty window, which no bound admits; escaped partitions, finished frames and idle lanes carry the bound 0)
-    uint32_t zlim = (escw < 0) ? (uint32_t)(32 - k) : 0u;
+    // (The window arithmetic below is right for any code whose stop bit lies in the first 32 bits -- up to 64 bits long; what
+    // limits the fast path is the top-up budget: at least 513 bits are resident after a top-up, 8 samples of at most
+    // kFastBits = 40 bits + 8 partition parameters + the 96 bits of the last window stay inside.  At 32 bits -- the limit of
+    // rounds 1-3 -- data of nearly full range, Rice parameters of 29-30 and codes of 31-34 bits, left the fast path at every
+    // sample: the low words of the int64 benchmark array decoded at a third of the speed.)
+    constexpr int kFastBits = (kChunkBytes == 64) ? 40 : 32;
+    auto zlim_for = [&](int kk) __attribute__((always_inline)) -> uint32_t {
+        const int lim = kFastBits - kk;
+        return (uint32_t)(lim < 32 ? (lim > 0 ? lim : 0) : 32);
+    };
+    uint32_t zlim = (escw < 0) ? zlim_for(k) : 0u;
 
     // one sample of every lane.  GUARD: lanes may be in warm-up or past their frame's end.
     // PART: a partition boundary may fall inside this macro step (decided once per step for the wave)
@@ -1073,14 +1116,33 @@ __global__ __launch_bounds__(64) FA_K7_WAVES_ATTR void decode_frames_kernel(Deco
         if (live) {
             // rare events are tested wave-wide first, so the common case carries no exec-mask code
             if (PART && __builtin_expect(__any(pleft <= 0), 0)) {
-                if (pleft <= 0) {
-                    const ParamRet pr = slow_param(cbase, lim16, ring, bitpos, next_chunk, plen, esc);
-                    k = (int)pr.k;
-                    escw = (int)pr.escw;  // -1: plain Rice partition
-                    zlim = (escw < 0) ? (uint32_t)(32 - k) : 0u;
-                    bitpos = pr.bitpos;
-                    next_chunk = pr.next_chunk;
-                    pleft += ps;
+                // A partition starts with its Rice parameter, plen bits at the lane's position -- the top of the window
+                // the sample would read.  Taken from the window in place (the top-up budget covers it: 8 samples x 32 bits
+                // + 8 parameters x 5 bits of the 512 resident); only an ESCAPED partition (parameter all ones, a raw
+                // width follows) goes through the general reader.  (Round 4: through slow_param for every partition, a
+                // frame of 16-32 partitions spent more time there -- one lane at a time -- than in its samples: 2x on
+                // the reference's demo data, 5x on the quiet high words of int64 arrays.)
+                const bool np = pleft <= 0;
+                const uint32_t A0 = __builtin_amdgcn_alignbit(pw0, pw1, (~(bitpos - 1)) & 31);
+                const uint32_t kk = A0 >> ((32 - plen) & 31);
+                if (__builtin_expect(__any(np && (int)kk == esc), 0)) {
+                    if (np) {
+                        const ParamRet pr = slow_param(cbase, lim16, ring, bitpos, next_chunk, plen, esc);
+                        k = (int)pr.k;
+                        kp1 = pr.k + 1u;
+                        escw = (int)pr.escw;  // -1: plain Rice partition
+                        zlim = (escw < 0) ? zlim_for(k) : 0u;
+                        bitpos = pr.bitpos;
+                        next_chunk = pr.next_chunk;
+                        pleft += ps;
+                    }
+                } else {
+                    k = np ? (int)kk : k;
+                    kp1 = np ? kk + 1u : kp1;
+                    escw = np ? -1 : escw;
+                    zlim = np ? zlim_for((int)kk) : zlim;
+                    bitpos += np ? (uint32_t)plen : 0u;
+                    pleft += np ? ps : 0;
                 }
                 ring_words(lane4, bitpos, pw0, pw1, pw2);
             }
@@ -1105,7 +1167,7 @@ __global__ __launch_bounds__(64) FA_K7_WAVES_ATTR void decode_frames_kernel(Deco
             const uint32_t low = __builtin_amdgcn_ubfe(X, (uint32_t)((32 - k) & 31), (uint32_t)k);
             const uint32_t uu = ((uint32_t)z << k) | low;
             int32_t r = (int32_t)(uu >> 1) ^ -(int32_t)(uu & 1);
-            uint32_t nbp = bitpos + (uint32_t)(z + 1 + k);
+            uint32_t nbp = bitpos + (uint32_t)z + kp1;
             double radd = 0.0;  // NCH == 2: what a 33-bit VERBATIM sample adds to its low word
             // one compare for both the wave vote and (inside the rare branch only) the lane's own answer
             const uint64_t okm = __ballot(fastok);
@@ -1321,6 +1383,9 @@ __global__ __launch_bounds__(64) FA_K7_WAVES_ATTR void decode_frames_kernel(Deco
         const int need = (hi_max + kStep - 1) / kStep * kStep;
         if (need < end) end = need;
     }
+    if constexpr (NCH == 2) {
+        if (!__any(mode != 3)) end = 0;  // nothing to decode in this channel for any lane of the wave
+    }
     int main_lo = (32 + MACRO - 1) / MACRO * MACRO;
     if (main_lo > end) main_lo = end;
     int main_hi = (bs_min < bs_max ? bs_min : bs_max) / MACRO * MACRO;
@@ -1342,9 +1407,105 @@ __global__ __launch_bounds__(64) FA_K7_WAVES_ATTR void decode_frames_kernel(Deco
             }
         }
     }
+    if constexpr (NCH == 2) {
+        if (skipped) {  // on to the second subframe: the reader state at its first bit
+            bitpos = resume_bitpos;
+            next_chunk = ring_ensure(cbase, lim16, ring, bitpos, bitpos >> kChunkShift);
+        }
+    }
     }  // channel loop
     if constexpr (NCH == 2) {
         if (has_task && task_live) a.assign[task] = ch_assign;  // both subframes decoded
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K7v (two-channel arrays): VERBATIM first subframes, one lane per sample.
+// A lane of K7 walks its frame sample by sample whatever the subframe holds, and a VERBATIM sample goes through the escape
+// branch of its loop: ~3x the cost of a Rice-coded one.  But a VERBATIM subframe is bs fields of bps bits at known
+// positions -- and the low word of an int64 sample (channel 0, utils.c:96-123) is VERBATIM whenever the data is finer than
+// 32 bits, i.e. for most float64 arrays.  One workgroup per task reads the frame header (its length only: K7 validates it),
+// and if the first subframe is VERBATIM without wasted bits writes the wanted samples into K7's planar image and their
+// bit 32 (33-bit side channels; the sign otherwise) into the bit image; K7 steps over such a subframe (`verbatim_done`).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void verbatim_channel0_kernel(DecodeArgs a) {
+    const int64_t task = blockIdx.x;
+    int64_t s, f, sl_first, sl_last;
+    if (a.task_stream) {
+        s = a.task_stream[task]; f = a.task_frame[task];
+        sl_first = a.task_first[task]; sl_last = a.task_last[task];
+    } else {
+        s = task / a.nfr; f = a.f0 + (task - s * a.nfr);
+        sl_first = a.first; sl_last = a.first + a.n_decode;
+    }
+    const StreamMeta m = a.meta[s];
+    const int64_t at = a.ftab[s * a.nf + f];
+    // (Every early return below is a frame that K7 either rejects or does not treat as "VERBATIM first subframe" itself: K7
+    // skips the subframe only if it read the byte 0x02 at this same position from inside the blob.)
+    if (m.first_frame < 0 || at < 0 || at + 5 > a.blob_bytes) return;
+    const uint8_t* const p = a.blob + at;
+    const uint32_t b2 = p[2], b3 = p[3], u0 = p[4];
+    const int bsc = (int)(b2 >> 4), src = (int)(b2 & 15), ch = (int)(b3 >> 4), ssc = (int)((b3 >> 1) & 7);
+    if (p[0] != 0xFF || p[1] != 0xF8 || (ch != 1 && ch != 8 && ch != 9 && ch != 10)) return;
+    int extra = 0;
+    if (u0 & 0x80) {
+        int mbit = 0x40;
+        while ((u0 & mbit) && extra < 7) { extra++; mbit >>= 1; }
+        if (extra == 0 || extra > 6) return;
+    }
+    const int hl = 4 + 1 + extra + (bsc == 6 ? 1 : bsc == 7 ? 2 : 0) + (src == 12 ? 1 : (src == 13 || src == 14) ? 2 : 0) + 1;
+    if (at + hl + 1 > a.blob_bytes || p[hl] != 0x02) return;  // the first subframe: VERBATIM (type 000001), no wasted bits
+    int fbps;
+    switch (ssc) {
+        case 0: fbps = m.bps; break;
+        case 1: fbps = 8; break;
+        case 2: fbps = 12; break;
+        case 4: fbps = 16; break;
+        case 5: fbps = 20; break;
+        case 6: fbps = 24; break;
+        case 7: fbps = 32; break;
+        default: return;
+    }
+    const int bps = fbps + (ch == 9 ? 1 : 0);  // side / right: channel 0 is the side channel, one bit wider
+    if (bps <= 0 || bps > 33) return;
+    const int64_t fstart = f * (int64_t)a.B;
+    int64_t bs = a.stream_size - fstart;
+    if (bs > a.B) bs = a.B;
+    int64_t lo = sl_first - fstart, hi = sl_last - fstart;
+    if (lo < 0) lo = 0;
+    if (hi > bs) hi = bs;
+    if (hi <= lo) return;
+    int32_t* const t0 = a.out_i32 + (task * 2 + 0) * (int64_t)a.B;
+    uint32_t* const h0 = a.hibits + (task * 2 + 0) * (int64_t)a.hib_words;
+    const uint64_t bit0 = 8ull * (uint64_t)(hl + 1);
+    const int lane = threadIdx.x & 63;
+    // whole words of the bit image: samples [lo rounded down to 32, hi rounded up to 32), clipped to the block
+    const int64_t i0 = lo & ~(int64_t)31;
+    const int64_t i1 = ((hi + 31) & ~(int64_t)31) < ((bs + 31) & ~(int64_t)31) ? ((hi + 31) & ~(int64_t)31) : ((bs + 31) & ~(int64_t)31);
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {  // (i1 - i0 is a multiple of 32: a wave's lanes 0-31 / 32-63 stay together)
+        uint32_t low = 0;
+        bool neg = false;
+        if (i < bs) {
+            const uint64_t bp = bit0 + (uint64_t)i * (uint64_t)bps;
+            const int64_t q = at + (int64_t)(bp >> 3);
+            uint64_t w = 0;  // eight bytes from q, big endian (the field starts up to 7 bits in and is at most 33 bits long)
+            if (q + 8 <= a.blob_bytes) {
+                uint32_t r0, r1;
+                __builtin_memcpy(&r0, a.blob + q, 4);
+                __builtin_memcpy(&r1, a.blob + q + 4, 4);
+                w = ((uint64_t)__builtin_bswap32(r0) << 32) | __builtin_bswap32(r1);
+            } else {
+                for (int k = 0; k < 8; ++k) w = (w << 8) | (q + k < a.blob_bytes ? a.blob[q + k] : 0u);
+            }
+            const uint64_t v = (w << (bp & 7)) >> (64 - bps);  // the field, right-aligned
+            neg = ((v >> (bps - 1)) & 1) != 0;
+            // low 32 bits of the sign-extended value
+            low = (bps >= 32) ? (uint32_t)v : (uint32_t)((int32_t)((uint32_t)v << (32 - bps)) >> (32 - bps));
+            if (i >= lo && i < hi) t0[i] = (int32_t)low;
+        }
+        const uint64_t bal = __ballot(neg);
+        if (lane == 0) h0[i >> 5] = (uint32_t)bal;
+        if (lane == 32) h0[i >> 5] = (uint32_t)(bal >> 32);
     }
 }
 

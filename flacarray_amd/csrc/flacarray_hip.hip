@@ -740,6 +740,10 @@ int decode_device_impl(const unsigned char* d_bytes, int64_t n_bytes, const int6
         a.assign = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(p8) + tmp_b + hib_b);
         FA_HIP_TRY(hipMemsetAsync(a.assign, 0xFF, (size_t)a.n_tasks * 4, st));
         prof_begin(2, st);
+        if (std::getenv("FLACARRAY_HIP_NO_VERBATIM_KERNEL") == nullptr) {  // (diagnostic: K7 alone decodes everything)
+            hipLaunchKernelGGL(verbatim_channel0_kernel, dim3((unsigned)a.n_tasks), dim3(256), 0, st, a);
+            a.verbatim_done = 1;
+        }
         hipLaunchKernelGGL((decode_frames_kernel<8, -1, false, 2>), dim3(nblk), dim3(64), 0, st, a, d_err + 1);
         prof_end(2, st);
         FA_HIP_TRY(hipMemcpyAsync(h_err, d_err, 16, hipMemcpyDeviceToHost, st));
