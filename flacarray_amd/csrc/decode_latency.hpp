@@ -61,25 +61,32 @@ struct LatInline {
 // come out of one ds_read2_b32 as the low and high half of a 64-bit register pair in the order the shift wants them
 // (forward order costs a swap and its wait state per window, and a window is read for every code of the parse).
 constexpr uint32_t kLatTop = (uint32_t)(kLatImgWords + kLatPadWords - 1);
+// (two-channel frames: a VERBATIM low word and whatever the high word takes -- the image is twice as long; TOP is the index
+// of the image's last word, i.e. of the frame's word 0)
+constexpr int kLatImgWords2 = 2 * kLatImgWords;
+constexpr uint32_t kLatTop2 = (uint32_t)(kLatImgWords2 + kLatPadWords - 1);
+template <uint32_t TOP>
 __device__ __forceinline__ uint32_t lat_win(const uint32_t* img, uint32_t pos) {  // bits [pos, pos + 32)
     uint32_t wi = pos >> 5;
-    wi = wi < kLatTop - 1u ? wi : kLatTop - 1u;  // (zero words behind the frame)
-    const uint32_t* const q = img + (kLatTop - 1u - wi);  // q[0] = word wi + 1, q[1] = word wi
+    wi = wi < TOP - 1u ? wi : TOP - 1u;  // (zero words behind the frame)
+    const uint32_t* const q = img + (TOP - 1u - wi);  // q[0] = word wi + 1, q[1] = word wi
     const uint64_t v = ((uint64_t)q[1] << 32) | q[0];
     return (uint32_t)((v << (pos & 31)) >> 32);
 }
 // the same for positions known to lie inside the image (the walks of the parse stop at the frame's end)
+template <uint32_t TOP>
 __device__ __forceinline__ uint32_t lat_win_in(const uint32_t* img, uint32_t pos) {
-    const uint32_t* const q = img + (kLatTop - 1u - (pos >> 5));
+    const uint32_t* const q = img + (TOP - 1u - (pos >> 5));
     const uint64_t v = ((uint64_t)q[1] << 32) | q[0];
     return (uint32_t)((v << (pos & 31)) >> 32);
 }
 
 // length of the Rice code that starts at bit p (0 = no stop bit within reach: not a code)
+template <uint32_t TOP>
 __device__ __forceinline__ uint32_t lat_code_len(const uint32_t* img, uint32_t p, uint32_t k, uint32_t lim) {
     uint32_t q = 0, A;
     for (;;) {
-        A = lat_win(img, p + q);
+        A = lat_win<TOP>(img, p + q);
         if (A != 0 || p + q >= lim || q > kLatUnaryMax) break;
         q += 32;
     }
@@ -204,7 +211,9 @@ struct LatWide {
 // mid / side (a shift of a 33-bit sum) stays with K7.  F32 then means "float64 output".
 template <bool F32, int NCH>
 __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInline inl, LatWide wd, int* fallback) {
-    __shared__ __attribute__((aligned(16))) uint32_t img[kLatImgWords + kLatPadWords];
+    constexpr int kImgWords = (NCH == 2) ? kLatImgWords2 : kLatImgWords;
+    constexpr uint32_t kTop = (NCH == 2) ? kLatTop2 : kLatTop;
+    __shared__ __attribute__((aligned(16))) uint32_t img[kImgWords + kLatPadWords];
     __shared__ __attribute__((aligned(16))) int32_t res_all[NCH][kLatMaxBlock + kLatResPad];
     __shared__ double coef_s[16];  // pre-scaled coefficients, zero from the order on
     const int lane = threadIdx.x;
@@ -243,7 +252,7 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
     const int64_t base = at & ~(int64_t)15;
     const uint32_t skip = (uint32_t)(at - base);
     const uint32_t nbytes = skip + (uint32_t)(nxt - at);
-    if (nbytes > (uint32_t)kLatImgWords * 4u) { give_up(1); return; }
+    if (nbytes > (uint32_t)kImgWords * 4u) { give_up(1); return; }
     const uint32_t frame_end_bits = nbytes * 8u;  // (includes the CRC-16; an upper bound is all that is needed)
 
     // ---- frame image: coalesced 16-byte loads, big-endian words ----
@@ -266,13 +275,13 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
                 const uint32_t i = i0 + 64u * (uint32_t)t + (uint32_t)lane;
                 if (i < pieces) {
                     uint4 o;
-                    // words 4 i .. 4 i + 3 go to img[kLatTop - 4 i - 3 .. kLatTop - 4 i], highest word first
+                    // words 4 i .. 4 i + 3 go to img[kTop - 4 i - 3 .. kTop - 4 i], highest word first
                     o.w = __builtin_bswap32(d[t].x); o.z = __builtin_bswap32(d[t].y); o.y = __builtin_bswap32(d[t].z); o.x = __builtin_bswap32(d[t].w);
-                    *reinterpret_cast<uint4*>(&img[kLatTop - 3u - 4u * i]) = o;
+                    *reinterpret_cast<uint4*>(&img[kTop - 3u - 4u * i]) = o;
                 }
             }
         }
-        for (uint32_t i = 4 * pieces + lane; i < (uint32_t)(kLatImgWords + kLatPadWords); i += 64) img[kLatTop - i] = 0;
+        for (uint32_t i = 4 * pieces + lane; i < (uint32_t)(kImgWords + kLatPadWords); i += 64) img[kTop - i] = 0;
     }
     __syncthreads();
     FA_LAT_STAMP(1);
@@ -282,7 +291,7 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
     bool bad = false;
     auto get = [&](int n) __attribute__((always_inline)) -> uint32_t {  // n in 1..32
         if (pos + (uint32_t)n > frame_end_bits) { bad = true; return 0u; }
-        const uint32_t v = lat_win(img, pos) >> (32 - n);
+        const uint32_t v = lat_win<kTop>(img, pos) >> (32 - n);
         pos += (uint32_t)n;
         return v;
     };
@@ -388,10 +397,10 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
     } else if (tc == 1) {  // VERBATIM: fixed-width fields, one lane per sample
         if (pos + (uint32_t)bps * (uint32_t)bs > frame_end_bits) { give_up(4); return; }
         if (bps > 32) {  // a 33-bit side channel: the low 32 bits of every field
-            for (int i = lo + lane; i < hi; i += 64) res[i] = (int32_t)lat_win(img, pos + (uint32_t)i * 33u + 1u);
+            for (int i = lo + lane; i < hi; i += 64) res[i] = (int32_t)lat_win<kTop>(img, pos + (uint32_t)i * 33u + 1u);
         } else {
             for (int i = lo + lane; i < hi; i += 64) {
-                const uint32_t v = lat_win(img, pos + (uint32_t)i * (uint32_t)bps) >> (32 - bps);
+                const uint32_t v = lat_win<kTop>(img, pos + (uint32_t)i * (uint32_t)bps) >> (32 - bps);
                 res[i] = (int32_t)(v << (32 - bps)) >> (32 - bps);
             }
         }
@@ -438,7 +447,7 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
                 for (uint32_t i = lane; i < n; i += 64) {
                     int32_t v = 0;
                     if (wbits) {
-                        const uint32_t u = lat_win(img, pos + i * (uint32_t)wbits) >> (32 - wbits);
+                        const uint32_t u = lat_win<kTop>(img, pos + i * (uint32_t)wbits) >> (32 - wbits);
                         v = (int32_t)(u << (32 - wbits)) >> (32 - wbits);
                     }
                     res[idx0 + i] = v;
@@ -509,7 +518,7 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
                         auto step = [&]() __attribute__((always_inline)) -> bool {
                             ended = ended || q0 >= lim;  // (behind the frame: zeros, no code)
                             const bool go = !ended && q0 < limw;
-                            const uint32_t A = lat_win_in(img, ended ? 0u : q0);
+                            const uint32_t A = lat_win_in<kTop>(img, ended ? 0u : q0);
                             const bool adv = go && A != 0;
                             slow = slow || (go && A == 0);  // 32 zeros or more: the general reader below
                             q0 += adv ? (uint32_t)__clz((int)A) + 1u + k : 0u;
@@ -523,7 +532,7 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
                         (void)step();
                         if (__builtin_expect(__builtin_amdgcn_ballot_w64(slow) != 0, 0)) {
                             if (slow) {
-                                const uint32_t len = lat_code_len(img, q0, k, lim);
+                                const uint32_t len = lat_code_len<kTop>(img, q0, k, lim);
                                 if (len == 0) ended = true;
                                 else { q0 += len; c++; }
                             }
@@ -581,13 +590,13 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
                         const bool go = mine && !bad_lane && pe < seg_end && j < todo;
                         if (__builtin_amdgcn_ballot_w64(go) == 0) break;
                         const uint32_t pin = (go && pe < lim) ? pe : 0u;  // (a true code starts inside the frame)
-                        uint32_t A = lat_win_in(img, pin);
+                        uint32_t A = lat_win_in<kTop>(img, pin);
                         uint32_t z = (uint32_t)__clz((int)A);
                         if (__builtin_expect(__builtin_amdgcn_ballot_w64(go && A == 0) != 0, 0)) {  // 32 zeros or more somewhere: the general reader
                             if (go) {
                                 uint32_t q = 0;
                                 for (;;) {
-                                    A = lat_win(img, pe + q);
+                                    A = lat_win<kTop>(img, pe + q);
                                     if (A != 0 || pe + q >= lim || q > kLatUnaryMax) break;
                                     q += 32;
                                 }
@@ -596,7 +605,7 @@ __global__ __launch_bounds__(64) void decode_latency_kernel(DecodeArgs a, LatInl
                             }
                         }
                         const uint32_t lowpos = pe + z + 1u;
-                        const uint32_t low = k ? (lat_win(img, (go && !bad_lane) ? lowpos : 0u) >> (32 - k)) : 0u;
+                        const uint32_t low = k ? (lat_win<kTop>(img, (go && !bad_lane) ? lowpos : 0u) >> (32 - k)) : 0u;
                         const uint32_t uu = (z << k) | low;
                         const bool put = go && !bad_lane;
                         // (lanes that are done store into the last pad word, which nobody reads)
