@@ -32,3 +32,26 @@ for name, x, kw in cases:
         tc.append(t1 - t0)
         td.append(t2 - t1)
     print(f"{name:36s} from_array {min(tc) * 1e3:8.3f} ms   to_array {min(td) * 1e3:8.3f} ms   ({f.nbytes / x.nbytes:.3f} of the raw size)")
+# small reads from a host-resident store (the reference's usage: array.py:409-449) and from the same store resident in HBM
+x = rng.normal(0, 1, (1000, 100000)).astype(np.float32)
+f = fa.FlacArray.from_array(x, quanta=1e-7)
+keep = np.zeros(1000, dtype=bool)
+keep[500] = True
+for name, fn in (("host store: f[500, 1000:2000]", lambda: f[500, 1000:2000]), ("host store: f[500]  (whole stream)", lambda: f[500]),
+                 ("host store: to_array(keep=one stream)", lambda: f.to_array(keep=keep))):
+    fn()
+    ts = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        y = fn()
+        ts.append(time.perf_counter() - t0)
+    print(f"{name:44s} {np.median(ts) * 1e3:8.3f} ms")
+f.to_device()
+for name, fn in (("resident store: f[500, 1000:2000]", lambda: f[500, 1000:2000]), ("resident store: f[500]  (whole stream)", lambda: f[500])):
+    fn()
+    ts = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        y = fn()
+        ts.append(time.perf_counter() - t0)
+    print(f"{name:44s} {np.median(ts) * 1e3:8.3f} ms")
