@@ -35,6 +35,9 @@ SYMBOLS = [
     "fa_encode_workspace_bytes_i64",
     "fa_encode_i64_device_begin",
     "fa_encode_i64_device_finish",
+    "fa_encode_capacity_bytes_i64",
+    "fa_encode_single_pass_workspace_bytes_i64",
+    "fa_encode_i64_device",
     "fa_float64_to_int64_device",
     "fa_int64_to_float64_device",
     "fa_decode_slices_i64_device",
@@ -121,6 +124,12 @@ def lib():
     L.fa_encode_single_pass_workspace_bytes.restype = i64
     L.fa_encode_i32_device.argtypes = [vp, i64, i64, u32, vp, i64, vp, i64, vp, vp, pi64, vp, vp]
     L.fa_encode_i32_device.restype = cint
+    if hasattr(L, "fa_encode_i64_device") or not os.environ.get("FLACARRAY_HIP_LIB"):  # (an older diagnostic build may lack them)
+        L.fa_encode_i64_device.argtypes = L.fa_encode_i32_device.argtypes
+        L.fa_encode_i64_device.restype = cint
+        for name in ("fa_encode_capacity_bytes_i64", "fa_encode_single_pass_workspace_bytes_i64"):
+            getattr(L, name).argtypes = [i64, i64, u32]
+            getattr(L, name).restype = i64
     L.fa_encode_f32_device.argtypes = [vp, i64, i64, u32, vp, vp, i64, vp, i64, vp, vp, vp, vp, pi64, vp, vp]
     L.fa_encode_f32_device.restype = cint
     L.fa_decode_i32_device.argtypes = [vp, i64, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, vp, cint]

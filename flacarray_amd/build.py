@@ -19,10 +19,11 @@ DEPS = [
 ]
 SRC_COMPACT = os.path.join(_HERE, "csrc", "compact_unit.hip")
 SRC_FUSED = os.path.join(_HERE, "csrc", "fused_unit.hip")
-DEPS += [SRC_COMPACT, SRC_FUSED, os.path.join(_HERE, "csrc", "encode_fused.hpp"), os.path.join(_HERE, "csrc", "verify_kernels.hpp"),
+SRC_PLACED = os.path.join(_HERE, "csrc", "placed_unit.hip")
+DEPS += [SRC_COMPACT, SRC_FUSED, SRC_PLACED, os.path.join(_HERE, "csrc", "encode_placed.hpp"), os.path.join(_HERE, "csrc", "encode_fused.hpp"), os.path.join(_HERE, "csrc", "verify_kernels.hpp"),
          os.path.join(_HERE, "csrc", "decode_latency.hpp")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared"]
-# The shipped library is built from three translation units: the slot encoder and the decoder (K3, K7) with LLVM's
+# The shipped library is built from four translation units (the fourth, the placing encoder K3G, like the first): the slot encoder and the decoder (K3, K7) with LLVM's
 # max-ILP scheduling strategy (measured: K3 -4 %, K7 -2 %), the compaction kernels (K5) and the single-pass encoder
 # (K3F, which has no registers to spare: 168 for three waves per SIMD) with the default one (max-ILP slows K5 by 10 %
 # and adds spills to K3F).  Variants (diagnostic builds) stay single-unit, default strategy.
@@ -50,7 +51,8 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cflags = [f for f in FLAGS if f != "-shared"]
     objs, procs = [], []
-    for src, extra in ((SRC, MAIN_UNIT_FLAGS), (SRC_COMPACT, []), (SRC_FUSED, [])):  # the units compile side by side
+    # (the units compile side by side; the placing encoder shares K3's frame body and is compiled like it)
+    for src, extra in ((SRC, MAIN_UNIT_FLAGS), (SRC_COMPACT, []), (SRC_FUSED, []), (SRC_PLACED, MAIN_UNIT_FLAGS)):
         obj = os.path.join(os.path.dirname(OUT), os.path.basename(src).replace(".hip", ".o"))
         cmd = [hipcc] + cflags + extra + ["-c", "-o", obj, src]
         if verbose:

@@ -1634,11 +1634,12 @@ void launch_fused_encode(hipStream_t st, const FusedArgs& a, bool f32)
 ;
 #endif
 void launch_fused_finish(hipStream_t st, uint8_t* out, const int64_t* frame_abs, const uint32_t* frame_bytes, int64_t n_stream,
-                         int64_t nframes, int64_t stream_size, int32_t tail_bs, int64_t hb, int64_t* starts, int64_t* nbytes, int64_t* total)
+                         int64_t nframes, int64_t stream_size, int32_t B, int32_t tail_bs, int32_t nch, int64_t hb, int64_t* starts,
+                         int64_t* nbytes, int64_t* total)
 #if defined(FA_UNIT_FUSED) || !defined(FA_SPLIT_UNITS)
 {
     hipLaunchKernelGGL(fused_finish_kernel, dim3((unsigned)n_stream), dim3(256), 0, st, out, frame_abs, frame_bytes, n_stream, nframes,
-                       stream_size, (int32_t)kMaxBlock, tail_bs, 1, hb, starts, nbytes, total);
+                       stream_size, B, tail_bs, nch, hb, starts, nbytes, total);
 }
 #else
 ;

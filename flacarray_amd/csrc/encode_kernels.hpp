@@ -568,17 +568,18 @@ __device__ __forceinline__ void load_frame(const int32_t* __restrict__ src, int 
 // other into the same bit ring.
 constexpr int kStereoSmall = 256;  // |low word| below this in the whole frame: the side + right trial is worth its analysis
 
-template <int MLO, int NCH = 1>
 #ifndef FA_K3_WAVES_ATTR
 #define FA_K3_WAVES_ATTR
 #endif
-FA_GLOBAL __global__ __launch_bounds__(64) FA_K3_WAVES_ATTR void encode_frames_kernel(EncodeArgs a) {
-    constexpr int kScrWords = (NCH == 2) ? 256 : 0;  // analysis scratch: the ring holds live bits while channel 1 is analysed
-#ifdef FA_LDS_PAD
-    __shared__ __attribute__((aligned(16))) int32_t lds[kLdsWords + kScrWords + FA_LDS_PAD];  // occupancy experiment
-#else
-    __shared__ __attribute__((aligned(16))) int32_t lds[kLdsWords + kScrWords];
-#endif
+template <int NCH>
+constexpr int k3_lds_words() { return kLdsWords + ((NCH == 2) ? 256 : 0); }  // (+ analysis scratch: the ring holds live bits while channel 1 is analysed)
+
+// One frame: frame g of the array (stream g / nframes, frame g % nframes) is analysed and packed into `slot` by the
+// calling wavefront; `lds` is the wave's frame image (k3_lds_words<NCH>() words), `lane` the lane number.  Returns the frame's bytes (the
+// CRC-16 field, the last two of them, is left zero: K5 / the placement step fills it in).  Callers: the slot kernel
+// below (one frame per workgroup) and the placing kernel of encode_placed.hpp (a ticket loop).
+template <int MLO, int NCH>
+__device__ __forceinline__ uint32_t encode_frame_body(const EncodeArgs& a, const int64_t g, uint8_t* const slot, int32_t* const lds, const int lane) {
     int32_t* smp = lds;
     uint32_t* ring = reinterpret_cast<uint32_t*>(lds + kSmpWords);
     uint64_t* psum = reinterpret_cast<uint64_t*>(lds + kSmpWords + kRingWords + 2);
@@ -586,8 +587,6 @@ FA_GLOBAL __global__ __launch_bounds__(64) FA_K3_WAVES_ATTR void encode_frames_k
     uint32_t* scr = (NCH == 2) ? reinterpret_cast<uint32_t*>(lds + kLdsWords) : ring;
     (void)psum;
 
-    const int lane = threadIdx.x;
-    const int64_t g = a.tail_only ? ((int64_t)blockIdx.x * a.nframes + a.nframes - 1) : (int64_t)blockIdx.x;
     // (the host keeps n_stream * nframes below 2^31: a 32-bit division, not the 64-bit software one)
     const int64_t s = (int64_t)((uint32_t)g / (uint32_t)a.nframes);
     const int64_t f = g - s * a.nframes;
@@ -599,7 +598,6 @@ FA_GLOBAL __global__ __launch_bounds__(64) FA_K3_WAVES_ATTR void encode_frames_k
 
     FA_STAMP_INIT;
     // frame-level writer state: bit position, flushed 256-byte blocks, the zeroed ring
-    uint8_t* slot = a.slots + (size_t)(a.tail_only ? (int64_t)blockIdx.x : g) * (size_t)a.slot_stride;
     uint32_t total_bytes = 0;
     uint32_t pos = 0;
     uint32_t blocks_flushed = 0;
@@ -1508,6 +1506,25 @@ FA_GLOBAL __global__ __launch_bounds__(64) FA_K3_WAVES_ATTR void encode_frames_k
         if (a.info)
             for (int c = 0; c < NCH; ++c) a.info[g * NCH + c].nbytes = (int32_t)total_bytes;
     }
+    return total_bytes;
+}
+
+template <int MLO, int NCH = 1>
+FA_GLOBAL __global__ __launch_bounds__(64) FA_K3_WAVES_ATTR void encode_frames_kernel(EncodeArgs a) {
+#ifdef FA_LDS_PAD
+    __shared__ __attribute__((aligned(16))) int32_t lds[k3_lds_words<NCH>() + FA_LDS_PAD];  // occupancy experiment
+#else
+    __shared__ __attribute__((aligned(16))) int32_t lds[k3_lds_words<NCH>()];
+#endif
+    const int64_t g = a.tail_only ? ((int64_t)blockIdx.x * a.nframes + a.nframes - 1) : (int64_t)blockIdx.x;
+    uint8_t* slot = a.slots + (size_t)(a.tail_only ? (int64_t)blockIdx.x : g) * (size_t)a.slot_stride;
+#ifdef FA_STAMPS  // diagnostic build: how many workgroups are alive at once (stamps[41] = the most seen)
+    if (threadIdx.x == 0 && a.stamps) atomicMax(&a.stamps[41], atomicAdd(&a.stamps[40], 1ULL) + 1ULL);
+#endif
+    (void)encode_frame_body<MLO, NCH>(a, g, slot, lds, (int)threadIdx.x);
+#ifdef FA_STAMPS
+    if (threadIdx.x == 0 && a.stamps) atomicAdd(&a.stamps[40], ~0ULL);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1629,7 +1646,6 @@ constexpr int kCrcTabWords = 2048;  // uint16 entries
 #endif
 constexpr int kK5Group = FA_K5_GROUP;
 
-#ifdef FA_HAVE_K5
 __device__ __forceinline__ uint16_t crc_mulmod(uint16_t a, uint16_t b) {
     uint32_t r = 0;
 #pragma unroll
@@ -1640,6 +1656,99 @@ __device__ __forceinline__ uint16_t crc_mulmod(uint16_t a, uint16_t b) {
     return (uint16_t)r;
 }
 
+// One frame, one wavefront: n bytes at srcw (a slot: word aligned, CRC field zero, readable in whole groups of GROUP
+// 256-byte blocks past the frame's end) go to dst (any byte alignment) with the CRC-16 filled in.  tab: the tables
+// above, in LDS.  Callers: K5 below, and the placing encoder (encode_placed.hpp), whose waves move their own frames.
+template <int GROUP = kK5Group>
+__device__ __forceinline__ void compact_one_frame(const int lane, const uint32_t* __restrict__ srcw, const uint32_t n, uint8_t* __restrict__ dst,
+                                                  const uint16_t* tab) {
+    const uint8_t* srcb = reinterpret_cast<const uint8_t*>(srcw);
+    const uint32_t L = n - 2;  // bytes covered by the CRC
+    // destination-aligned words: dst word w holds source bytes [hcopy + 4w, hcopy + 4w + 4)
+    const uint32_t head = (uint32_t)((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3);
+    const uint32_t hcopy = head < n ? head : n;
+    const uint32_t nw = (n - hcopy) >> 2;
+    uint32_t* dstw = reinterpret_cast<uint32_t*>(dst + hcopy);
+    const uint32_t sh = hcopy & 3;
+    // ---- one pass: CRC-16 over source bytes [0, L) and the copy of every full destination word
+    //      that does not contain a CRC byte; GROUP 256-byte blocks in flight per iteration ----
+    const uint32_t NB = (L + 255) >> 8;
+    uint16_t t = 0;
+    uint32_t last_full = 0;  // number of blocks in which this lane held a full word
+    uint16_t partial = 0;
+    for (uint32_t b0 = 0; b0 < NB; b0 += GROUP) {
+        uint32_t w[GROUP], w1[GROUP];
+#pragma unroll
+        for (int i = 0; i < GROUP; ++i) {
+            const uint32_t wi = 64u * (b0 + i) + (uint32_t)lane;  // source word index (slots and workspace have slack)
+            w[i] = srcw[wi];
+            w1[i] = srcw[wi + 1];
+        }
+#pragma unroll
+        for (int i = 0; i < GROUP; ++i) {
+            const uint32_t b = b0 + i;
+            const uint32_t o = 256u * b + 4u * (uint32_t)lane;
+            if (b < NB) {
+                if (o + 4 <= L) {
+#ifdef FA_K5_NOCRC  // timing experiment only (wrong CRC-16): what the six table lookups per word cost
+                    t = (uint16_t)(t ^ w[i] ^ (w[i] >> 16));
+#else
+                    const uint16_t adv = (uint16_t)(tab[1024 + (t >> 8)] ^ tab[1280 + (t & 255)]);
+                    const uint16_t c = (uint16_t)(tab[w[i] & 255] ^ tab[256 + ((w[i] >> 8) & 255)] ^ tab[512 + ((w[i] >> 16) & 255)] ^ tab[768 + (w[i] >> 24)]);
+                    t = (uint16_t)(adv ^ c);
+#endif
+                    last_full = b + 1;
+                }
+            }
+            // destination word that starts at source byte o + sh (needs o >= hcopy - sh, i.e. not before the head)
+            const uint32_t so = o + sh;  // source byte offset of this destination word
+            if (so >= hcopy && so + 4 <= L) {
+                const uint32_t v = sh ? __builtin_amdgcn_alignbyte(w1[i], w[i], sh) : w[i];
+                dstw[(so - hcopy) >> 2] = v;
+            }
+        }
+    }
+    // the one word that holds the last 1..3 bytes under the CRC (if L is not a multiple of 4): its lane reads it again
+    // here, so that the unrolled loop above carries no byte loop (code size: the placing encoder shares its instruction
+    // cache with a 58 KB frame body)
+    if ((L & 3u) != 0 && (uint32_t)lane == ((L >> 2) & 63u)) {
+        const uint32_t wl = srcw[L >> 2];
+        uint16_t c = 0;
+        for (uint32_t k = 0; k < (L & 3u); ++k) c = crc16_byte(c, (uint8_t)(wl >> (8 * k)));
+        partial = c;
+    }
+    uint16_t contrib = partial;
+    if (last_full > 0) {
+        const uint32_t after = L - (256u * (last_full - 1) + 4u * (uint32_t)lane + 4u);  // bytes after the lane's last word
+        contrib ^= crc_mulmod(t, tab[1536 + after]);
+    }
+    uint32_t cr = contrib;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) cr ^= (uint32_t)__shfl_xor((int)cr, off, 64);
+    const uint16_t crc = (uint16_t)cr;
+    // ---- edges: head bytes, the words around the CRC, tail bytes ----
+    if ((uint32_t)lane < hcopy) {
+        uint8_t v = srcb[lane];
+        if ((uint32_t)lane == n - 2) v = (uint8_t)(crc >> 8);
+        if ((uint32_t)lane == n - 1) v = (uint8_t)crc;
+        dst[lane] = v;
+    }
+    // bytes from the first destination word that was not written above to the end of the frame
+    uint32_t done = hcopy;  // first source byte not yet copied
+    if (L >= hcopy + 4) done = hcopy + (((L - hcopy) >> 2) << 2);
+    // the loop above wrote dst words with so + 4 <= L  <=>  (so - hcopy) / 4 < (L - hcopy) / 4 (so = hcopy + 4k)
+    const uint32_t rest = n - done;  // < 8 + 2
+    if ((uint32_t)lane < rest) {
+        const uint32_t bo = done + lane;
+        uint8_t v = srcb[bo];
+        if (bo == n - 2) v = (uint8_t)(crc >> 8);
+        if (bo == n - 1) v = (uint8_t)crc;
+        dst[bo] = v;
+    }
+    (void)nw;
+}
+
+#ifdef FA_HAVE_K5
 // (eight waves per SIMD: this kernel lives on memory-level parallelism, whatever the scheduling strategy of the build)
 FA_GLOBAL __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void compact_frames_kernel(const uint8_t* __restrict__ slots,
                                                              const uint32_t* __restrict__ frame_bytes,
@@ -1655,88 +1764,8 @@ FA_GLOBAL __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8
     const int64_t hb = stream_header_bytes(nframes);
     for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < total_frames; g += (int64_t)gridDim.x * 4) {
         const int64_t s = g / nframes;
-        const uint32_t n = frame_bytes[g];
-        const uint32_t* srcw = reinterpret_cast<const uint32_t*>(slots + (size_t)g * (size_t)slot_stride);
-        const uint8_t* srcb = reinterpret_cast<const uint8_t*>(srcw);
-        uint8_t* dst = out + starts[s] + hb + frame_off[g];
-        const uint32_t L = n - 2;  // bytes covered by the CRC
-        // destination-aligned words: dst word w holds source bytes [hcopy + 4w, hcopy + 4w + 4)
-        const uint32_t head = (uint32_t)((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3);
-        const uint32_t hcopy = head < n ? head : n;
-        const uint32_t nw = (n - hcopy) >> 2;
-        uint32_t* dstw = reinterpret_cast<uint32_t*>(dst + hcopy);
-        const uint32_t sh = hcopy & 3;
-        // ---- one pass: CRC-16 over source bytes [0, L) and the copy of every full destination word
-        //      that does not contain a CRC byte; kK5Group 256-byte blocks in flight per iteration ----
-        const uint32_t NB = (L + 255) >> 8;
-        uint16_t t = 0;
-        uint32_t last_full = 0;  // number of blocks in which this lane held a full word
-        uint16_t partial = 0;
-        for (uint32_t b0 = 0; b0 < NB; b0 += kK5Group) {
-            uint32_t w[kK5Group], w1[kK5Group];
-#pragma unroll
-            for (int i = 0; i < kK5Group; ++i) {
-                const uint32_t wi = 64u * (b0 + i) + (uint32_t)lane;  // source word index (slots and workspace have slack)
-                w[i] = srcw[wi];
-                w1[i] = srcw[wi + 1];
-            }
-#pragma unroll
-            for (int i = 0; i < kK5Group; ++i) {
-                const uint32_t b = b0 + i;
-                const uint32_t o = 256u * b + 4u * (uint32_t)lane;
-                if (b < NB) {
-                    if (o + 4 <= L) {
-#ifdef FA_K5_NOCRC  // timing experiment only (wrong CRC-16): what the six table lookups per word cost
-                        t = (uint16_t)(t ^ w[i] ^ (w[i] >> 16));
-#else
-                        const uint16_t adv = (uint16_t)(tab[1024 + (t >> 8)] ^ tab[1280 + (t & 255)]);
-                        const uint16_t c = (uint16_t)(tab[w[i] & 255] ^ tab[256 + ((w[i] >> 8) & 255)] ^ tab[512 + ((w[i] >> 16) & 255)] ^ tab[768 + (w[i] >> 24)]);
-                        t = (uint16_t)(adv ^ c);
-#endif
-                        last_full = b + 1;
-                    } else if (o < L) {
-                        uint16_t c = 0;
-                        for (uint32_t k = o; k < L; ++k) c = crc16_byte(c, (uint8_t)(w[i] >> (8 * (k - o))));
-                        partial = c;
-                    }
-                }
-                // destination word that starts at source byte o + sh (needs o >= hcopy - sh, i.e. not before the head)
-                const uint32_t so = o + sh;  // source byte offset of this destination word
-                if (so >= hcopy && so + 4 <= L) {
-                    const uint32_t v = sh ? __builtin_amdgcn_alignbyte(w1[i], w[i], sh) : w[i];
-                    dstw[(so - hcopy) >> 2] = v;
-                }
-            }
-        }
-        uint16_t contrib = partial;
-        if (last_full > 0) {
-            const uint32_t after = L - (256u * (last_full - 1) + 4u * (uint32_t)lane + 4u);  // bytes after the lane's last word
-            contrib ^= crc_mulmod(t, tab[1536 + after]);
-        }
-        uint32_t cr = contrib;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) cr ^= (uint32_t)__shfl_xor((int)cr, off, 64);
-        const uint16_t crc = (uint16_t)cr;
-        // ---- edges: head bytes, the words around the CRC, tail bytes ----
-        if ((uint32_t)lane < hcopy) {
-            uint8_t v = srcb[lane];
-            if ((uint32_t)lane == n - 2) v = (uint8_t)(crc >> 8);
-            if ((uint32_t)lane == n - 1) v = (uint8_t)crc;
-            dst[lane] = v;
-        }
-        // bytes from the first destination word that was not written above to the end of the frame
-        uint32_t done = hcopy;  // first source byte not yet copied
-        if (L >= hcopy + 4) done = hcopy + (((L - hcopy) >> 2) << 2);
-        // the loop above wrote dst words with so + 4 <= L  <=>  (so - hcopy) / 4 < (L - hcopy) / 4 (so = hcopy + 4k)
-        const uint32_t rest = n - done;  // < 8 + 2
-        if ((uint32_t)lane < rest) {
-            const uint32_t bo = done + lane;
-            uint8_t v = srcb[bo];
-            if (bo == n - 2) v = (uint8_t)(crc >> 8);
-            if (bo == n - 1) v = (uint8_t)crc;
-            dst[bo] = v;
-        }
-        (void)nw;
+        compact_one_frame(lane, reinterpret_cast<const uint32_t*>(slots + (size_t)g * (size_t)slot_stride), frame_bytes[g],
+                          out + starts[s] + hb + frame_off[g], tab);
     }
 }
 

@@ -1,0 +1,170 @@
+// encode_placed.hpp -- K3G: single-pass FLAC encode for every geometry K3F does not take (gfx950, wave64).
+//
+// K3F (encode_fused.hpp) covers full 4096-sample mono frames of levels 3-8.  Everything else the reference's arrays
+// produce -- streams shorter than two frames ((12, 1000), (1, 10000): src/flacarray/tests/bindings.py:165-230), the
+// 1152-sample blocks of levels 0-2, streams whose length is not a multiple of 4, rows that are not 16-byte aligned and
+// the two-channel frames of int64 / float64 arrays (compress.c:482-511) -- used to take the slot sequence: K3 packs
+// every frame into a worst-case slot (16.6 KB per channel and frame: 17 GB for the 4096 x 2^20 workload), K4 scans the
+// sizes in two launches, a device-to-host copy sizes the blob, K5 re-reads every slot from HBM and moves it.
+//
+// Here the wave that packed a frame also places it.  The grid is persistent (kPlacedGrid workgroups: what the chip
+// holds); every wave owns TWO slots and loops:
+//     ticket  -> frame number g (a device-wide counter, so frames are handed out in start order)
+//     K3's frame body (encode_frame_body, unchanged: same decisions, same bits) packs frame g into one slot
+//     size_pub[g] <- bytes; the scanner wave (ticket 0, K3F's fused_scanner) turns published sizes into byte offsets
+//     the frame packed ONE TRIP AGO, waiting in the other slot: off_pub[g'] -> its absolute offset (it has had a whole
+//                    frame body's time to arrive: the scanner's latency and the spread of the frames before it are
+//                    hidden), and the wave moves it there (K5's per-frame copy: byte shift + CRC-16).
+// Progress: let u be the smallest frame not yet published; the wave that holds its ticket is either packing it (and will
+// publish without waiting for anybody) or -- the ticket is drawn one step early -- waiting for the offset of the frame it
+// packed before, which is smaller than u, so everything before THAT is published and the scanner delivers.  No dependence on dispatch order; time-outs raise the error word and every wave terminates.
+// Slots: 2 x grid x 16.6 KB (x 2 for two channels) = 68-136 MB instead of one per frame; no K4, no K5, no size
+// read-back before the blob is written.  The bytes are those of the slot sequence (tests pin one to the other).
+#pragma once
+#include "encode_fused.hpp"
+
+namespace fa {
+
+// The persistent grid: 8 workgroups (20 KB of LDS each) on each of 256 CUs.  Not asked of the occupancy API, which answers
+// 3-4 per CU for this kernel on this stack (it reckons with 64 KB of LDS) -- a grid that size ran the frame bodies at half
+// the chip.  A grid larger than what is resident is harmless: a workgroup draws its first ticket when it starts, so the
+// ones that wait for a free CU hold no frame anybody could be waiting for.
+constexpr int kPlacedGrid = 2048;
+constexpr int kPlacedGroup = 16;  // 256-byte blocks the placement copy keeps in flight (the frame body's registers are free by then)
+
+#if defined(FA_UNIT_PLACED) || !defined(FA_SPLIT_UNITS)
+// p: the placement half of K3F's argument block (total_frames, nframes, n_stream, hb, blob, capacity, frame_abs,
+// ticket, size_pub, off_pub, total, err, info); p.crc_tab holds K5's tables here (kCrcTabWords entries).
+#ifndef FA_PG_ATTR
+#define FA_PG_ATTR FA_K3_WAVES_ATTR
+#endif
+template <int MLO, int NCH>
+__global__ __launch_bounds__(64) FA_PG_ATTR void encode_placed_kernel(EncodeArgs a, FusedArgs p) {
+    __shared__ __attribute__((aligned(16))) int32_t lds[k3_lds_words<NCH>()];
+    static_assert(kCrcTabWords / 2 <= kSmpWords, "the CRC tables overlay the frame image");
+    const int lane = threadIdx.x;
+    // two slots per workgroup: the frame packed last waits in one for its offset while the next is packed into the other
+    uint8_t* const slot0 = a.slots + (size_t)blockIdx.x * 2 * (size_t)a.slot_stride;
+    uint16_t* const tab = reinterpret_cast<uint16_t*>(lds);  // K5's tables take the frame image's place once the frame is packed
+#ifdef FA_STAMPS  // diagnostic build: cycles per phase of the loop, summed over the frames of every 64th workgroup (stamps[20..25])
+    unsigned long long pg_[6] = {0, 0, 0, 0, 0, 0}, pt_ = fa_memtime();
+    if (lane == 0 && p.stamps) {  // when did this workgroup start?  (100 MHz ticks after the first one: histogram of 2.5 ms bins in stamps[32..39])
+        const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long old_ = atomicCAS(&p.stamps[28], 0ULL, now_);
+        const unsigned long long rel_ = old_ ? now_ - old_ : 0ULL;
+        const int b_ = (int)(rel_ / 250000ULL);
+        atomicAdd(&p.stamps[32 + (b_ > 7 ? 7 : b_)], 1ULL);
+    }
+#define FA_PG_STAMP(k) do { const unsigned long long n_ = fa_memtime(); pg_[k] += n_ - pt_; pt_ = n_; } while (0)
+#define FA_PG_FLUSH do { if (lane == 0 && p.stamps) { if ((blockIdx.x & 63) == 1) for (int i_ = 0; i_ < 6; ++i_) atomicAdd(&p.stamps[20 + i_], pg_[i_]); if (pg_[5]) atomicAdd(&p.stamps[26], 1ULL); atomicMax(&p.stamps[27], pg_[5]); } } while (0)
+#else
+#define FA_PG_STAMP(k) do { } while (0)
+#define FA_PG_FLUSH do { } while (0)
+#endif
+    int64_t g_wait = -1;  // the frame that waits in the other slot (published, not placed yet)
+    uint32_t n_wait = 0;
+    int cur = 0;
+    // One ticket = one frame.  (Four consecutive frames per ticket -- a quarter of the atomics on the one counter -- ran
+    // 400 x slower: a wave waits for an offset between two frames of its ticket, so publishing frame 4k+3 came to depend
+    // on frame 4k-1 being published, a serial chain through every ticket.)  The next ticket is drawn BEFORE the placement
+    // step and looked at after it, so the counter's latency (microseconds: every wave of the chip draws from it) is hidden.
+    uint32_t t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        if (t == 0) {  // the first wave to start is the scanner; when it is done every frame has its offset
+            fused_scanner(p, lane);
+            return;
+        }
+        const int64_t g = (int64_t)t - 1;
+        const bool have = g < p.total_frames;
+        FA_PG_STAMP(0);  // ticket
+        uint32_t n = 0;
+        if (have) {
+            // (the lane number is recomputed per frame behind an asm the optimiser cannot see through: taken from threadIdx.x,
+            // every lane-dependent address and mask of the frame body is invariant in this loop, gets hoisted out of it and
+            // lives in registers across the whole body -- 257 instead of 169 registers, i.e. one wave per SIMD instead of two)
+            const int lane_f = lane_id_opaque();
+            __builtin_assume(lane_f >= 0 && lane_f < 64);
+            n = encode_frame_body<MLO, NCH>(a, g, slot0 + (size_t)cur * (size_t)a.slot_stride, lds, lane_f);
+            // a frame is published as soon as it is packed, before this wave waits for anything: whoever holds a ticket
+            // publishes without depending on anybody, so every wait below ends
+            if (lane == 0) __hip_atomic_store(p.size_pub + g, 0x80000000u | n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        FA_PG_STAMP(1);  // frame body
+        if (have && lane == 0) t = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the next trip's)
+        if (g_wait >= 0) {
+            // ---- place the frame packed one trip ago: its offset has had a whole frame body's time to arrive ----
+            lds_fence();  // (the writer's last LDS reads are done: the image may go)
+            for (int i = lane; i < kCrcTabWords / 2; i += 64) reinterpret_cast<uint32_t*>(tab)[i] = reinterpret_cast<const uint32_t*>(p.crc_tab)[i];
+            FA_PG_STAMP(2);  // tables
+            unsigned long long off = 0;
+            for (uint32_t spins = 0;; ++spins) {
+                off = lb_load(p.off_pub + g_wait);
+                off = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
+                if (off) break;
+                if (spins > kLbSpinLimit) break;
+                if ((spins & 1023u) == 1023u && (lb_load(p.err) & 6)) return;  // somebody timed out: nothing behind it will get an offset
+                __builtin_amdgcn_s_sleep(FA_F_SLEEP);
+            }
+            FA_PG_STAMP(3);  // wait for the offset
+            if (!off) {
+                if (lane == 0) atomicOr(p.err, 2);
+                return;
+            }
+            if ((int64_t)off + (int64_t)n_wait > p.capacity) {  // the caller's buffer is too small: sized, not written
+                if (lane == 0) atomicOr(p.err, 1);
+            } else {
+                // The slot's stores before its loads: both are this wave's and go through this CU's write-through L1, which
+                // keeps a CU coherent with itself, so ordering is all it takes (workgroup scope = s_waitcnt).  Agent scope
+                // here would write back and invalidate the whole XCD's L2 once per frame and wave (measured: 2x the run time).
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                compact_one_frame<kPlacedGroup>(lane, reinterpret_cast<const uint32_t*>(slot0 + (size_t)(cur ^ 1) * (size_t)a.slot_stride), n_wait,
+                                                p.blob + off, tab);
+                if (lane == 0) p.frame_abs[g_wait] = (int64_t)off;
+            }
+            lds_fence();  // (the table reads are done before the next frame's image overwrites them)
+            FA_PG_STAMP(4);  // placement
+#ifdef FA_STAMPS
+            pg_[5] += 1;
+#endif
+        }
+        if (!have) { FA_PG_FLUSH; return; }
+        g_wait = g;
+        n_wait = n;
+        cur ^= 1;
+    }
+}
+#endif
+
+void launch_encode_placed(hipStream_t st, const EncodeArgs& a, const FusedArgs& p, int nch, int64_t grid)
+#if defined(FA_UNIT_PLACED) || !defined(FA_SPLIT_UNITS)
+{
+    const dim3 g((unsigned)grid), b(64);
+#ifdef FA_DEV_MINIMAL
+    hipLaunchKernelGGL((encode_placed_kernel<8, 1>), g, b, 0, st, a, p);
+#else
+    if (nch == 1) {
+        switch (a.max_lpc_order) {
+            case 0: hipLaunchKernelGGL((encode_placed_kernel<0, 1>), g, b, 0, st, a, p); break;
+            case 6: hipLaunchKernelGGL((encode_placed_kernel<6, 1>), g, b, 0, st, a, p); break;
+            case 8: hipLaunchKernelGGL((encode_placed_kernel<8, 1>), g, b, 0, st, a, p); break;
+            default: hipLaunchKernelGGL((encode_placed_kernel<12, 1>), g, b, 0, st, a, p); break;
+        }
+    } else {
+        switch (a.max_lpc_order) {
+            case 0: hipLaunchKernelGGL((encode_placed_kernel<0, 2>), g, b, 0, st, a, p); break;
+            case 6: hipLaunchKernelGGL((encode_placed_kernel<6, 2>), g, b, 0, st, a, p); break;
+            case 8: hipLaunchKernelGGL((encode_placed_kernel<8, 2>), g, b, 0, st, a, p); break;
+            default: hipLaunchKernelGGL((encode_placed_kernel<12, 2>), g, b, 0, st, a, p); break;
+        }
+    }
+#endif
+}
+#else
+;
+#endif
+
+}  // namespace fa

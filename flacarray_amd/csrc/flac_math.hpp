@@ -16,7 +16,7 @@
 
 // Non-template kernels defined in headers that more than one translation unit includes get internal linkage in the
 // secondary units (the unit that launches them keeps the external definition).
-#if defined(FA_UNIT_FUSED)
+#if defined(FA_UNIT_FUSED) || defined(FA_UNIT_PLACED)
 #define FA_GLOBAL static
 #else
 #define FA_GLOBAL

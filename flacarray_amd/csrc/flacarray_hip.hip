@@ -32,6 +32,7 @@
 #endif
 #include "encode_kernels.hpp"
 #include "encode_fused.hpp"
+#include "encode_placed.hpp"
 #include "decode_latency.hpp"
 #include "quantize_kernels.hpp"
 #include "verify_kernels.hpp"
@@ -306,6 +307,7 @@ struct FusedPlan {
     int64_t capacity;
 };
 
+static bool slots_forced() { return std::getenv("FLACARRAY_HIP_SLOTS") != nullptr; }  // diagnostic: K3 + K4 + K5 for everything
 // f32: float32 input (quantised in the staging load of K3F only: whole frames).  int32 streams may end in a short
 // frame -- the slot encoder writes those, K3F the rest -- if every frame still starts on a 16-byte boundary.
 bool fused_geometry(int64_t n_stream, int64_t stream_size, uint32_t level, bool f32 = false) {
@@ -314,7 +316,7 @@ bool fused_geometry(int64_t n_stream, int64_t stream_size, uint32_t level, bool 
     const int64_t nf = (stream_size + kMaxBlock - 1) / kMaxBlock;
     if (18 * nf >= (1 << 24)) return false;
     if (nf > 0x7fffffffLL / n_stream) return false;
-    return std::getenv("FLACARRAY_HIP_SLOTS") == nullptr;  // diagnostic: force the slot path (K3 + K4 + K5)
+    return !slots_forced();
 }
 
 void make_fused_plan(int64_t n_stream, int64_t stream_size, uint32_t level, FusedPlan* pl) {
@@ -343,6 +345,54 @@ void make_fused_plan(int64_t n_stream, int64_t stream_size, uint32_t level, Fuse
     pl->capacity = pl->F * (int64_t)kSlotBytes + n_stream * pl->hb;
 }
 
+
+// ---- single-pass encode of every other geometry (encode_placed.hpp): K3's frame body, frames placed by their waves ----
+struct PlacedPlan {
+    LevelParams P;
+    int64_t nf, F, hb, slot_stride;
+    int tail_bs;
+    size_t off_fbytes, off_fabs, off_zero, off_size, off_off, off_ticket, zero_bytes, off_total, off_slots, total;
+    int64_t capacity;
+};
+
+// the persistent grid (+ the scanner's workgroup), never more than frames + scanner
+int64_t placed_grid(int64_t F) {
+    int64_t g = kPlacedGrid;
+    if (const char* e = std::getenv("FLACARRAY_HIP_PLACED_GRID")) {  // diagnostic: another grid (64 .. 16384 workgroups)
+        const long v = std::atol(e);
+        if (v >= 64 && v <= 16384) g = v;
+    }
+    return std::min<int64_t>(g, F) + 1;
+}
+
+int make_placed_plan(int64_t n_stream, int64_t stream_size, uint32_t level, int nch, PlacedPlan* pl) {
+    if (level > 8) return FA_ERROR_INVALID_LEVEL;
+    if (n_stream <= 0) return FA_ERROR_ZERO_NSTREAM;
+    if (stream_size <= 0) return FA_ERROR_ZERO_STREAMSIZE;
+    pl->P = level_params(level);
+    const int64_t B = pl->P.blocksize;
+    pl->nf = (stream_size + B - 1) / B;
+    pl->tail_bs = (int)(stream_size - (pl->nf - 1) * B);
+    if (18 * pl->nf >= (1 << 24)) return FA_ERROR_ENCODE_PROCESS;  // SEEKTABLE block length is 24 bit
+    if (pl->nf > 0x7fffffffLL / n_stream) return FA_ERROR_ENCODE_PROCESS;  // 32-bit frame numbers (tickets: + the grid, still 32 bit); the host API chunks
+    pl->F = n_stream * pl->nf;
+    pl->hb = stream_header_bytes(pl->nf);
+    pl->slot_stride = (int64_t)kSlotBytes * nch;
+    size_t o = 0;
+    pl->off_fbytes = o; o = align_up(o + (size_t)pl->F * 4, 256);
+    pl->off_fabs = o;   o = align_up(o + (size_t)pl->F * 8, 256);
+    pl->off_zero = o;   // everything from here to off_total is zeroed before every launch
+    pl->off_size = o;   o = align_up(o + (size_t)pl->F * 4, 256);
+    pl->off_off = o;    o = align_up(o + (size_t)pl->F * 8, 256);
+    pl->off_ticket = o; o = align_up(o + 16, 256);  // ticket word, error flags
+    pl->zero_bytes = o - pl->off_zero;
+    pl->off_total = o;  o = align_up(o + 8, 256);
+    // two slots per workgroup of the persistent grid + the placement copy's reads past the last slot's end
+    pl->off_slots = o;  o = align_up(o + (size_t)placed_grid(pl->F) * 2 * (size_t)pl->slot_stride + 256 * (size_t)kPlacedGroup + 256, 256);
+    pl->total = o;
+    pl->capacity = pl->F * pl->slot_stride + n_stream * pl->hb;
+    return FA_ERROR_NONE;
+}
 
 // optional CRC-16 check of every frame the decode just read (verify_kernels.hpp); h_err receives the refreshed flags
 // verify: 1 = check, 0 = do not, negative = the process default (fa_set_decode_verify)
@@ -1036,29 +1086,39 @@ int fa_encode_i64_device_finish(int64_t n_stream, int64_t stream_size, uint32_t 
     return encode_device_finish(2, n_stream, stream_size, level, d_workspace, d_starts, d_bytes, stream);
 }
 
+// Every valid geometry has a single-pass encoder: K3F (full mono frames of levels 3-8) or K3G (the rest).
 int fa_encode_single_pass_supported(int64_t n_stream, int64_t stream_size, uint32_t level) {
-    return fused_geometry(n_stream, stream_size, level) ? 1 : 0;
+    PlacedPlan pl;
+    return (make_placed_plan(n_stream, stream_size, level, 1, &pl) == FA_ERROR_NONE && !slots_forced()) ? 1 : 0;
 }
 
-int64_t fa_encode_capacity_bytes(int64_t n_stream, int64_t stream_size, uint32_t level) {
-    if (level > 8 || n_stream <= 0 || stream_size <= 0) return -1;
-    if (fused_geometry(n_stream, stream_size, level)) {
+static int64_t capacity_bytes_for(int64_t n_stream, int64_t stream_size, uint32_t level, int nch) {
+    PlacedPlan pl;
+    if (make_placed_plan(n_stream, stream_size, level, nch, &pl) != FA_ERROR_NONE) return -1;
+    return pl.capacity;  // every frame VERBATIM: one slot per frame and channel + the stream headers (K3F's figure is the same)
+}
+int64_t fa_encode_capacity_bytes(int64_t n_stream, int64_t stream_size, uint32_t level) { return capacity_bytes_for(n_stream, stream_size, level, 1); }
+int64_t fa_encode_capacity_bytes_i64(int64_t n_stream, int64_t stream_size, uint32_t level) { return capacity_bytes_for(n_stream, stream_size, level, 2); }
+
+// The workspace serves whichever sequence the call takes: K3F's, K3G's (also what K3F's geometries take when the rows
+// are not 16-byte aligned), or -- FLACARRAY_HIP_SLOTS -- the slot sequence's.
+static int64_t single_pass_workspace_for(int64_t n_stream, int64_t stream_size, uint32_t level, int nch) {
+    if (slots_forced()) return nch == 2 ? fa_encode_workspace_bytes_i64(n_stream, stream_size, level) : fa_encode_workspace_bytes(n_stream, stream_size, level);
+    PlacedPlan pp;
+    if (make_placed_plan(n_stream, stream_size, level, nch, &pp) != FA_ERROR_NONE) return -1;
+    int64_t need = (int64_t)pp.total;
+    if (nch == 1 && fused_geometry(n_stream, stream_size, level)) {
         FusedPlan pl;
         make_fused_plan(n_stream, stream_size, level, &pl);
-        return pl.capacity;
+        need = std::max<int64_t>(need, (int64_t)pl.total);
     }
-    EncodePlan pl;
-    if (make_plan(n_stream, stream_size, level, &pl) != FA_ERROR_NONE) return -1;
-    return pl.F * (int64_t)kSlotBytes + n_stream * stream_header_bytes(pl.nf);
+    return need;
 }
-
 int64_t fa_encode_single_pass_workspace_bytes(int64_t n_stream, int64_t stream_size, uint32_t level) {
-    if (fused_geometry(n_stream, stream_size, level)) {
-        FusedPlan pl;
-        make_fused_plan(n_stream, stream_size, level, &pl);
-        return (int64_t)pl.total;
-    }
-    return fa_encode_workspace_bytes(n_stream, stream_size, level);
+    return single_pass_workspace_for(n_stream, stream_size, level, 1);
+}
+int64_t fa_encode_single_pass_workspace_bytes_i64(int64_t n_stream, int64_t stream_size, uint32_t level) {
+    return single_pass_workspace_for(n_stream, stream_size, level, 2);
 }
 
 // the single-pass sequence: (float32 input: range pre-pass K1a/K1b,) zero the publish words, K3F, stream headers
@@ -1197,7 +1257,8 @@ static int fused_encode_run(const void* d_data, bool f32, const float* d_quanta,
         if (nblk > 32768) nblk = 32768;
         launch_compact_frames(st, nblk, reinterpret_cast<const uint8_t*>(ws + pl.off_tslots), tb, toff, tzero, 1, n_stream, crc5, d_bytes, kSlotBytes);
     }
-    launch_fused_finish(st, d_bytes, a.frame_abs, a.frame_bytes, n_stream, pl.nf, stream_size, (int32_t)pl.tail_bs, pl.hb, d_starts, d_nbytes, d_total);
+    launch_fused_finish(st, d_bytes, a.frame_abs, a.frame_bytes, n_stream, pl.nf, stream_size, (int32_t)kMaxBlock, (int32_t)pl.tail_bs, 1, pl.hb,
+                        d_starts, d_nbytes, d_total);
     prof_end(3, st);
     int h_nan = 0;
     FA_HIP_TRY(hipMemcpyAsync(&h_err, a.err, 4, hipMemcpyDeviceToHost, st));
@@ -1214,21 +1275,122 @@ static int fused_encode_run(const void* d_data, bool f32, const float* d_quanta,
 }
 
 
+// the single-pass sequence of every geometry K3F does not take: zero the publish words, K3G, stream headers
+static int placed_encode_run(const int32_t* d_data, int nch, int64_t n_stream, int64_t stream_size, uint32_t level, void* d_workspace,
+                             int64_t workspace_bytes, unsigned char* d_bytes, int64_t capacity_bytes, int64_t* d_starts,
+                             int64_t* d_nbytes, int64_t* h_total_bytes, int32_t* d_info, void* stream) {
+    FA_API_LOCK;
+    PlacedPlan pl;
+    int rc = make_placed_plan(n_stream, stream_size, level, nch, &pl);
+    if (rc) return rc;
+    if (!d_workspace || workspace_bytes < (int64_t)pl.total) return FA_ERROR_ALLOC;
+    if (!d_bytes || capacity_bytes < n_stream * pl.hb + 64) return FA_ERROR_ALLOC;  // (as for K3F: the buffer may gamble, but holds the headers)
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    char* ws = reinterpret_cast<char*>(d_workspace);
+    prof_begin(3, st);
+    FA_HIP_TRY(hipMemsetAsync(ws + pl.off_zero, 0, pl.zero_bytes, st));
+    EncodeArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.data = d_data; a.n_stream = n_stream; a.stream_size = stream_size; a.nframes = pl.nf;
+    a.B = pl.P.blocksize; a.tail_bs = pl.tail_bs;
+    a.max_lpc_order = pl.P.max_lpc_order; a.max_porder = pl.P.max_porder; a.precision = pl.P.qlp_precision;
+    rc = get_window(a.B, &a.win);
+    if (rc) return rc;
+    rc = get_window(a.tail_bs, &a.win_tail);
+    if (rc) return rc;
+    a.slots = reinterpret_cast<uint8_t*>(ws + pl.off_slots);
+    a.slot_stride = pl.slot_stride;
+    a.frame_bytes = reinterpret_cast<uint32_t*>(ws + pl.off_fbytes);
+    a.info = reinterpret_cast<FrameInfo*>(d_info);
+    a.pmax_full = max_porder_for(a.B, a.max_porder, 0);
+    a.pmax_tail = max_porder_for(a.tail_bs, a.max_porder, 0);
+    a.escale_full = 0.5 / (double)a.B;
+    a.escale_tail = 0.5 / (double)a.tail_bs;
+    {
+        // frame header fields by frame number (as in encode_device_begin: tabulated on the host, cached on the device)
+        void* dp = nullptr;
+        const size_t ntab = (size_t)pl.nf * (nch == 2 ? 2 : 1);
+        rc = get_scratch(9, ntab * sizeof(uint4) + 256, &dp);
+        if (rc) return rc;
+        if (ds_->c_nf != pl.nf || ds_->c_B != a.B || ds_->c_tail != a.tail_bs || ds_->c_nch != nch || ds_->c_dp != dp ||
+            ds_->c_epoch != ds_->scratch_epoch) {
+            ds_->h_hdr.resize(ntab);
+            for (int64_t f = 0; f < pl.nf; ++f) {
+                ds_->h_hdr[(size_t)f] = frame_header_entry((uint64_t)f, (f == pl.nf - 1) ? a.tail_bs : a.B, nch);
+                if (nch == 2) ds_->h_hdr[(size_t)(pl.nf + f)] = frame_header_entry((uint64_t)f, (f == pl.nf - 1) ? a.tail_bs : a.B, nch, true);
+            }
+            FA_HIP_TRY(hipMemcpyAsync(dp, ds_->h_hdr.data(), ntab * sizeof(uint4), hipMemcpyHostToDevice, st));
+            FA_HIP_TRY(hipStreamSynchronize(st));  // h_hdr is reused by the next call
+            ds_->c_nf = pl.nf; ds_->c_B = a.B; ds_->c_tail = a.tail_bs; ds_->c_nch = nch; ds_->c_dp = dp; ds_->c_epoch = ds_->scratch_epoch;
+        }
+        a.hdr = reinterpret_cast<const uint4*>(dp);
+    }
+    FusedArgs p;
+    std::memset(&p, 0, sizeof p);
+    p.n_stream = n_stream; p.stream_size = stream_size; p.nframes = pl.nf; p.total_frames = pl.F;
+    p.blob = d_bytes; p.capacity = capacity_bytes; p.hb = pl.hb;
+    p.frame_bytes = a.frame_bytes;
+    p.frame_abs = reinterpret_cast<int64_t*>(ws + pl.off_fabs);
+    p.info = a.info;
+    p.size_pub = reinterpret_cast<uint32_t*>(ws + pl.off_size);
+    p.off_pub = reinterpret_cast<unsigned long long*>(ws + pl.off_off);
+    p.total = reinterpret_cast<int64_t*>(ws + pl.off_total);
+    p.ticket = reinterpret_cast<uint32_t*>(ws + pl.off_ticket);
+    p.err = reinterpret_cast<int*>(ws + pl.off_ticket + 8);
+    rc = get_crc_tab(&p.crc_tab);  // (K5's tables: the placement step is K5's per-frame copy)
+    if (rc) return rc;
+#ifdef FA_STAMPS
+    {
+        void* sp = nullptr;
+        if (get_scratch(6, 512, &sp) == 0) {
+            if (!ds_->stamps_zeroed) { (void)hipMemset(sp, 0, 512); ds_->stamps_zeroed = true; }
+            p.stamps = reinterpret_cast<unsigned long long*>(sp);
+            a.stamps = p.stamps;  // (the frame body's own phases: stamps[0..16], as in the slot kernel)
+            (void)hipMemsetAsync(p.stamps + 28, 0, 8, st);  // (start time of the call's first workgroup)
+        }
+    }
+#endif
+    prof_begin(0, st);
+    launch_encode_placed(st, a, p, nch, placed_grid(pl.F));
+    prof_end(0, st);
+    int h_err = 0;
+    int64_t h_tot = 0;
+    FA_HIP_TRY(hipMemcpyAsync(&h_err, p.err, 4, hipMemcpyDeviceToHost, st));
+    FA_HIP_TRY(hipMemcpyAsync(&h_tot, p.total, 8, hipMemcpyDeviceToHost, st));
+    FA_HIP_TRY(hipStreamSynchronize(st));
+    FA_HIP_TRY(hipGetLastError());
+    if (h_err == 1 || (h_err == 0 && h_tot > capacity_bytes)) return FA_ERROR_ALLOC;  // the blob does not fit the caller's buffer
+    if (h_err) {
+        std::fprintf(stderr, "flacarray_hip: single-pass encode failed (flags %d: 1 = offset outside the buffer, 2 = a frame timed out waiting for its offset, 4 = the scanner timed out)\n", h_err);
+        return FA_ERROR_ENCODE_PROCESS;
+    }
+    launch_fused_finish(st, d_bytes, p.frame_abs, p.frame_bytes, n_stream, pl.nf, stream_size, (int32_t)a.B, (int32_t)pl.tail_bs, (int32_t)nch, pl.hb,
+                        d_starts, d_nbytes, p.total);
+    prof_end(3, st);
+    FA_HIP_TRY(hipMemcpyAsync(h_total_bytes, p.total, 8, hipMemcpyDeviceToHost, st));
+    FA_HIP_TRY(hipStreamSynchronize(st));
+    FA_HIP_TRY(hipGetLastError());
+    return FA_ERROR_NONE;
+}
+
 int fa_encode_i32_device(const int32_t* d_data, int64_t n_stream, int64_t stream_size, uint32_t level, void* d_workspace,
                          int64_t workspace_bytes, unsigned char* d_bytes, int64_t capacity_bytes, int64_t* d_starts,
                          int64_t* d_nbytes, int64_t* h_total_bytes, int32_t* d_info, void* stream) {
     if (level > 8) return FA_ERROR_INVALID_LEVEL;
     if (n_stream <= 0) return FA_ERROR_ZERO_NSTREAM;
     if (stream_size <= 0) return FA_ERROR_ZERO_STREAMSIZE;
-    if (!fused_geometry(n_stream, stream_size, level) || (reinterpret_cast<uintptr_t>(d_data) & 15)) {
-        // frames the single-pass kernel does not cover (short blocks of levels 0-2, tail frames, unaligned rows):
-        // the slot path, into the same caller-provided buffer
+    if (slots_forced()) {  // diagnostic: the slot sequence into the same caller-provided buffer
         int rc = encode_device_begin(d_data, 1, n_stream, stream_size, level, d_workspace, workspace_bytes, d_starts, d_nbytes,
                                      h_total_bytes, d_info, stream);
         if (rc) return rc;
         if (*h_total_bytes > capacity_bytes) return FA_ERROR_ALLOC;
         return encode_device_finish(1, n_stream, stream_size, level, d_workspace, d_starts, d_bytes, stream);
     }
+    // frames K3F does not cover (short blocks of levels 0-2, streams shorter than two frames, lengths that are not a multiple
+    // of 4, unaligned rows): K3G
+    if (!fused_geometry(n_stream, stream_size, level) || (reinterpret_cast<uintptr_t>(d_data) & 15))
+        return placed_encode_run(d_data, 1, n_stream, stream_size, level, d_workspace, workspace_bytes, d_bytes, capacity_bytes, d_starts,
+                                 d_nbytes, h_total_bytes, d_info, stream);
     return fused_encode_run(d_data, false, nullptr, nullptr, nullptr, n_stream, stream_size, level, d_workspace, workspace_bytes, d_bytes,
                             capacity_bytes, d_starts, d_nbytes, h_total_bytes, d_info, stream);
 }
@@ -1245,6 +1407,24 @@ int fa_encode_f32_device(const float* d_data, int64_t n_stream, int64_t stream_s
     if (!fused_geometry(n_stream, stream_size, level, true) || (reinterpret_cast<uintptr_t>(d_data) & 15)) return FA_ERROR_ENCODE_INIT;
     return fused_encode_run(d_data, true, d_quanta, d_offsets, d_gains, n_stream, stream_size, level, d_workspace, workspace_bytes, d_bytes,
                             capacity_bytes, d_starts, d_nbytes, h_total_bytes, d_info, stream);
+}
+
+int fa_encode_i64_device(const int64_t* d_data, int64_t n_stream, int64_t stream_size, uint32_t level, void* d_workspace,
+                         int64_t workspace_bytes, unsigned char* d_bytes, int64_t capacity_bytes, int64_t* d_starts,
+                         int64_t* d_nbytes, int64_t* h_total_bytes, int32_t* d_info, void* stream) {
+    if (level > 8) return FA_ERROR_INVALID_LEVEL;
+    if (n_stream <= 0) return FA_ERROR_ZERO_NSTREAM;
+    if (stream_size <= 0) return FA_ERROR_ZERO_STREAMSIZE;
+    const int32_t* d32 = reinterpret_cast<const int32_t*>(d_data);
+    if (slots_forced()) {
+        int rc = encode_device_begin(d32, 2, n_stream, stream_size, level, d_workspace, workspace_bytes, d_starts, d_nbytes, h_total_bytes,
+                                     d_info, stream);
+        if (rc) return rc;
+        if (*h_total_bytes > capacity_bytes) return FA_ERROR_ALLOC;
+        return encode_device_finish(2, n_stream, stream_size, level, d_workspace, d_starts, d_bytes, stream);
+    }
+    return placed_encode_run(d32, 2, n_stream, stream_size, level, d_workspace, workspace_bytes, d_bytes, capacity_bytes, d_starts, d_nbytes,
+                             h_total_bytes, d_info, stream);
 }
 
 int fa_decode_i32_device(const unsigned char* d_bytes, int64_t n_bytes, const int64_t* d_starts,
@@ -1675,8 +1855,8 @@ static int encode_host(const void* data_v, int nch, int64_t n_stream, int64_t st
     const size_t in_b = (size_t)chunk * stream_bytes;
     const size_t in_slot = align_up(in_b, 256);
     if ((rc = get_scratch(0, 2 * in_slot + 256, &d_in2))) return rc;
-    const int64_t wsb = (nch == 2) ? fa_encode_workspace_bytes_i64(chunk, stream_size, level)
-                                   : fa_encode_single_pass_workspace_bytes(chunk, stream_size, level);  // (the slot path's size when that runs)
+    const int64_t wsb = single_pass_workspace_for(chunk, stream_size, level, nch);  // (the slot sequence's size when that is forced)
+    if (wsb < 0) return FA_ERROR_ENCODE_PROCESS;
     if ((rc = get_scratch(5, (size_t)wsb, &d_ws))) return rc;
     if ((rc = get_scratch(4, (size_t)chunk * 40 + 1024, &d_aux))) return rc;
     int64_t* d_starts = reinterpret_cast<int64_t*>(d_aux);
@@ -1687,14 +1867,12 @@ static int encode_host(const void* data_v, int nch, int64_t n_stream, int64_t st
     double* d_q64 = reinterpret_cast<double*>(d_nb + chunk);  // (the float64 form uses the same region: three doubles per stream)
     double* d_off64 = d_q64 + chunk;
     double* d_gain64 = d_off64 + chunk;
-    const int64_t cap_chunk = (nch == 1) ? fa_encode_capacity_bytes(chunk, stream_size, level)
-                                         : chunk * one.nf * (int64_t)kSlotBytes * 2 + chunk * stream_header_bytes(one.nf);
+    const int64_t cap_chunk = capacity_bytes_for(chunk, stream_size, level, nch);
     if ((rc = get_scratch(3, (size_t)cap_chunk + 256, &d_out))) return rc;
     if (((f32 && !fused_f32) || f64) && (rc = get_scratch(11, in_b + 256, &d_int))) return rc;
 
     // the blob: worst case reserved (address space only), populated ahead of the copies, trimmed at the end
-    const int64_t cap_total = (nch == 1 ? fa_encode_capacity_bytes(n_stream, stream_size, level)
-                                        : n_stream * one.nf * (int64_t)kSlotBytes * 2 + n_stream * stream_header_bytes(one.nf)) + 64;
+    const int64_t cap_total = n_stream * one.nf * (int64_t)kSlotBytes * nch + n_stream * stream_header_bytes(one.nf) + 64;
     unsigned char* blob = reinterpret_cast<unsigned char*>(std::malloc((size_t)cap_total));
     bool reserved = (blob != nullptr);
     if (!reserved) {  // no overcommit: fall back to growing the blob chunk by chunk
@@ -1760,10 +1938,8 @@ static int encode_host(const void* data_v, int nch, int64_t n_stream, int64_t st
                     hipMemcpy(gains64 + s0, d_gain64, (size_t)ns * 8, hipMemcpyDeviceToHost) != hipSuccess) { err = FA_ERROR_DEVICE; break; }
                 src64 = d_int;
             }
-            err = encode_device_begin(reinterpret_cast<const int32_t*>(src64), nch, ns, stream_size, level, d_ws, wsb, d_starts, d_nb, &total, nullptr, nullptr);
-            if (err) break;
-            if (total > cap_chunk) { err = FA_ERROR_ALLOC; break; }
-            err = encode_device_finish(nch, ns, stream_size, level, d_ws, d_starts, reinterpret_cast<unsigned char*>(d_out), nullptr);
+            err = fa_encode_i64_device(reinterpret_cast<const int64_t*>(src64), ns, stream_size, level, d_ws, wsb, reinterpret_cast<unsigned char*>(d_out),
+                                       cap_chunk, d_starts, d_nb, &total, nullptr, nullptr);
             if (err) break;
         }
         if (n_chunks > 1) {

@@ -508,13 +508,13 @@ def encode_flac_device(data, level=5, workspace=None, return_info=False, compact
     device, starts/nbytes with the leading shape of `data` (at least 1-D) -- the device-resident
     analogue of encode_flac (libflacarray.pyx:529-594).
 
-    int32 input at levels 3-8 whose streams are at least two frames long and a multiple of 4 samples takes the
-    single-pass kernel (a short last frame goes through a slot and is moved into place afterwards): the frames are
-    written straight to their final offsets inside a buffer sized for the worst case, and `compressed` is the view
-    [0, total) of that buffer (it keeps the whole buffer alive; `compact=True` returns an exact-size copy instead).
-    `capacity_bytes` sizes that buffer instead of the worst case (1.016 x the input: every frame VERBATIM): if the blob
-    does not fit, nothing outside the buffer is written and the call raises "Encoding failed, return code = 1"
-    (ERROR_ALLOC) -- retry without it.  Everything else runs the slot sequence (K3, K4, K5) and returns an exact-size tensor.
+    Every geometry is encoded in a single pass (K3F for full 4096-sample mono frames of levels 3-8, K3G for the rest:
+    short streams, levels 0-2, int64; include/flacarray_hip.h): the frames end up at their final offsets inside a buffer
+    sized for the worst case, and `compressed` is the view [0, total) of that buffer (it keeps the whole buffer alive;
+    `compact=True` returns an exact-size copy instead).  `capacity_bytes` sizes that buffer instead of the worst case
+    (1.016 x the input: every frame VERBATIM): if the blob does not fit, nothing outside the buffer is written and the
+    call raises "Encoding failed, return code = 1" (ERROR_ALLOC) -- retry without it.  Under FLACARRAY_HIP_SLOTS (the
+    diagnostic cross-check) everything runs the slot sequence (K3, K4, K5) and returns an exact-size tensor.
     """
     torch = _torch()
     if data.dtype != torch.int32 and data.dtype != torch.int64:
@@ -543,14 +543,14 @@ def encode_flac_device(data, level=5, workspace=None, return_info=False, compact
         nf = (stream_size + bs - 1) // bs
         info = torch.zeros((n_stream * nf * (2 if i64 else 1), 8), dtype=torch.int32, device=data.device)
     total = ctypes.c_int64(0)
-    if not i64 and data.data_ptr() % 16 == 0 and L.fa_encode_single_pass_supported(n_stream, stream_size, level):
-        cap = L.fa_encode_capacity_bytes(n_stream, stream_size, level)
+    if L.fa_encode_single_pass_supported(n_stream, stream_size, level) and hasattr(L, "fa_encode_i64_device"):
+        cap = (L.fa_encode_capacity_bytes_i64 if i64 else L.fa_encode_capacity_bytes)(n_stream, stream_size, level)
         if capacity_bytes is not None:
             cap = min(cap, int(capacity_bytes))
-        ws = workspace.get(L.fa_encode_single_pass_workspace_bytes(n_stream, stream_size, level), data.device)
+        ws = workspace.get((L.fa_encode_single_pass_workspace_bytes_i64 if i64 else L.fa_encode_single_pass_workspace_bytes)(n_stream, stream_size, level), data.device)
         with torch.cuda.device(data.device):
             buf = torch.empty(cap, dtype=torch.uint8, device=data.device)
-            errcode = L.fa_encode_i32_device(
+            errcode = (L.fa_encode_i64_device if i64 else L.fa_encode_i32_device)(
                 _dp(data), n_stream, stream_size, level, _dp(ws), ws.numel(), _dp(buf), cap, _dp(starts), _dp(nbytes),
                 ctypes.byref(total), _dp(info), _stream_ptr(),
             )

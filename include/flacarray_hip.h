@@ -107,15 +107,20 @@ int fa_encode_i32_device_begin(const int32_t* d_data, int64_t n_stream, int64_t 
 int fa_encode_i32_device_finish(int64_t n_stream, int64_t stream_size, uint32_t level, void* d_workspace,
                                 const int64_t* d_starts, unsigned char* d_bytes, void* stream);
 
-/* Single-pass encode.  When the geometry allows it (levels 3-8, 16-byte aligned input, stream_size a multiple of 4096 --
- * or a multiple of 4 and at least 8192, in which case every stream's short last frame takes a detour through a slot:
- * fa_encode_single_pass_supported) ONE kernel analyses every full frame, sizes it, finds its byte offset by a
- * look-back over the frames before it and writes it -- CRC-16 included -- to its final place in d_bytes; there is
- * no per-frame slot and no compaction pass.  The caller provides d_bytes with fa_encode_capacity_bytes() bytes
+/* Single-pass encode: ONE kernel analyses every frame, sizes it, obtains its byte offset from a look-back over the frames
+ * before it (a scanner wave turns published sizes into offsets) and the frame ends up -- CRC-16 included -- at its final
+ * place in d_bytes; no K4 scans, no K5 pass, no size read-back before the blob is written.  Two kernels share the work:
+ *   K3F  levels 3-8, 16-byte aligned rows, stream_size a multiple of 4096 -- or a multiple of 4 and at least 8192, in which
+ *        case every stream's short last frame takes a detour through a slot: the bitstream is written straight from the
+ *        wave's registers, there are no slots;
+ *   K3G  everything else (levels 0-2 = 1152-sample blocks, streams shorter than two frames, any length, unaligned rows,
+ *        and -- fa_encode_i64_device -- the two-channel frames of int64 arrays): K3's frame body packs the frame into
+ *        the wave's own slot (a few thousand slots in all, cache resident) and the wave moves it once its offset is known.
+ * fa_encode_single_pass_supported is 1 for every valid geometry (0 only under FLACARRAY_HIP_SLOTS, the diagnostic switch
+ * that sends everything through begin + finish).  The caller provides d_bytes with fa_encode_capacity_bytes() bytes
  * (worst case: every frame VERBATIM; a smaller buffer is accepted -- if the blob does not fit, nothing outside the
- * buffer is written and the call returns FA_ERROR_ALLOC) and a workspace of fa_encode_single_pass_workspace_bytes(); the encoded
- * triple is d_bytes[0, *h_total_bytes), d_starts, d_nbytes.  Other geometries run the begin/finish sequence into
- * the same buffers.  Same bytes as begin + finish in every case. */
+ * buffer is written and the call returns FA_ERROR_ALLOC) and a workspace of fa_encode_single_pass_workspace_bytes(); the
+ * encoded triple is d_bytes[0, *h_total_bytes), d_starts, d_nbytes.  Same bytes as begin + finish in every case. */
 int fa_encode_single_pass_supported(int64_t n_stream, int64_t stream_size, uint32_t level);
 int64_t fa_encode_capacity_bytes(int64_t n_stream, int64_t stream_size, uint32_t level);
 int64_t fa_encode_single_pass_workspace_bytes(int64_t n_stream, int64_t stream_size, uint32_t level);
@@ -166,6 +171,13 @@ int fa_encode_i64_device_begin(const int64_t* d_data, int64_t n_stream, int64_t 
                                int64_t* h_total_bytes, int32_t* d_info, void* stream);
 int fa_encode_i64_device_finish(int64_t n_stream, int64_t stream_size, uint32_t level, void* d_workspace,
                                 const int64_t* d_starts, unsigned char* d_bytes, void* stream);
+/* ... and the single-pass form (K3G; replaces FLAC__stream_encoder_process_interleaved on two channels,
+ * compress.c:482-540) with its capacity and workspace queries. */
+int64_t fa_encode_capacity_bytes_i64(int64_t n_stream, int64_t stream_size, uint32_t level);
+int64_t fa_encode_single_pass_workspace_bytes_i64(int64_t n_stream, int64_t stream_size, uint32_t level);
+int fa_encode_i64_device(const int64_t* d_data, int64_t n_stream, int64_t stream_size, uint32_t level, void* d_workspace,
+                         int64_t workspace_bytes, unsigned char* d_bytes, int64_t capacity_bytes, int64_t* d_starts,
+                         int64_t* d_nbytes, int64_t* h_total_bytes, int32_t* d_info, void* stream);
 
 /* Decode [first_sample,last_sample) (or everything when either is negative) of n_stream
  * streams.  Exactly one of d_out_i32 / d_out_f32 is non-NULL; with d_out_f32 the int32 ->

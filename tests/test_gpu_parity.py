@@ -454,6 +454,53 @@ def test_single_pass_and_slot_sequence_write_the_same_bytes(fa):
         assert torch.equal(fa.decode_flac_device(*a, x_.shape[1]).cpu(), torch.from_numpy(x_))
 
 
+def test_placing_encoder_and_slot_sequence_write_the_same_bytes(fa, oracle):
+    """K3G (K3's frame body in a ticket loop, frames moved into place by the waves that packed them) against the slot
+    sequence and the oracle on the geometries K3F does not take -- the reference's own test shapes ((12, 1000)-class
+    arrays and single 10 000-sample streams, tests/bindings.py:165-230), levels 0-2 (1152-sample blocks), lengths that
+    are not a multiple of 4, rows that are not 16-byte aligned, int64 (two-channel frames) -- and on more frames than the
+    persistent grid has workgroups, so that every slot is used many times."""
+    import torch
+
+    L = fa._lib.lib()
+    rng = np.random.default_rng(4242)
+    base = np.concatenate(
+        [sinusoid_noise_i32(12, 5000, seed=81), full_range_i32((12, 1500)), np.zeros((12, 1200), np.int32),
+         (sinusoid_noise_i32(12, 2304, seed=82, amp=64) * 8).astype(np.int32)], axis=1)  # (12, 10004)
+    wide = base.astype(np.int64) * 8192 + rng.integers(-4096, 4096, base.shape)
+    small64 = rng.integers(-100, 100, (5, 9001)).astype(np.int64)  # (side + right frames)
+    many = sinusoid_noise_i32(2600, 1152 * 2 + 7, seed=83)  # level 1: 7800 frames > 2048 workgroups
+    cases = [(base[:, :1000], 5), (base[:1, :10000], 5), (base[:, :1000], 0), (base, 1), (base, 2), (base[:, :4097], 3), (base[:, :8191], 8),
+             (base[:, :10001], 6), (base[:, :4096], 5), (wide[:, :1000], 5), (wide[:1, :10000], 5), (wide, 0), (wide, 3), (wide[:, :8192], 7),
+             (small64, 5), (many, 1), (many[:, :1000].astype(np.int64) << 20, 2)]
+    for xx, level in cases:
+        x_ = np.ascontiguousarray(xx)
+        d = torch.from_numpy(x_).cuda()
+        assert L.fa_encode_single_pass_supported(int(np.prod(x_.shape[:-1])), x_.shape[-1], level) == 1
+        a = fa.encode_flac_device(d, level=level)
+        os.environ["FLACARRAY_HIP_SLOTS"] = "1"
+        try:
+            assert L.fa_encode_single_pass_supported(int(np.prod(x_.shape[:-1])), x_.shape[-1], level) == 0
+            b = fa.encode_flac_device(d, level=level)
+        finally:
+            del os.environ["FLACARRAY_HIP_SLOTS"]
+        assert a[0].untyped_storage().size() > a[0].numel() == b[0].numel() == b[0].untyped_storage().size()
+        assert all(torch.equal(u, v) for u, v in zip(a, b)), (x_.shape, x_.dtype, level)
+        blob, st, nb = (oracle.encode_i64 if x_.dtype == np.int64 else oracle.encode_i32)(x_, level)
+        assert np.array_equal(a[0].cpu().numpy(), blob) and np.array_equal(a[1].cpu().numpy(), st) and np.array_equal(a[2].cpu().numpy(), nb)
+        assert torch.equal(fa.decode_flac_device(*a, x_.shape[1], is_int64=x_.dtype == np.int64).cpu(), torch.from_numpy(x_))
+    # rows that start 4 bytes off a 16-byte boundary (a view into a larger tensor): K3G instead of K3F, same bytes
+    big = torch.from_numpy(np.concatenate([np.zeros(1, np.int32), sinusoid_noise_i32(3, 8192, seed=84).reshape(-1)])).cuda()
+    view = big[1:].reshape(3, 8192)
+    assert view.data_ptr() % 16 == 4
+    a = fa.encode_flac_device(view, level=5)
+    b = fa.encode_flac_device(view.clone(), level=5)  # (aligned: K3F)
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+    # an undersized buffer is refused cleanly, as for K3F
+    with pytest.raises(RuntimeError, match="return code = 1"):
+        fa.encode_flac_device(torch.from_numpy(np.ascontiguousarray(full_range_i32((12, 1500)))).cuda(), level=1, capacity_bytes=12 * 100 + 4096)
+
+
 def test_corrupt_index_rejected(fa, oracle):
     """A damaged index (stream_starts / stream_nbytes pointing outside the blob, negative entries) must come
     back as ERROR_DECODE_INIT, never as an out-of-range device read."""
