@@ -101,6 +101,8 @@ struct FusedArgs {
     int* err;               // error flags (OR)
     const uint16_t* crc_tab;  // [kFCrcSlice + kFCrcXpow]
     unsigned long long* stamps;  // diagnostic build (-DFA_STAMPS): per-phase cycle sums
+    int64_t* starts;        // K3G only (encode_placed.hpp writes the stream index and headers itself): [n_stream]
+    int64_t* nbytes;        // K3G only: [n_stream]
 };
 
 // word index of 16-byte unit u (0..7) of chunk c1 (0 = zero history, 1 + l = A_l)

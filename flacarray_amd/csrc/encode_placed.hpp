@@ -18,6 +18,9 @@
 // Progress: let u be the smallest frame not yet published; the wave that holds its ticket is either packing it (and will
 // publish without waiting for anybody) or -- the ticket is drawn one step early -- waiting for the offset of the frame it
 // packed before, which is smaller than u, so everything before THAT is published and the scanner delivers.  No dependence on dispatch order; time-outs raise the error word and every wave terminates.
+// The wave that places a frame also writes the stream index and header fields that frame owns (its seek point; the
+// stream's fixed header and starts[] with the first frame, nbytes[] with the last): the whole encode is ONE launch after
+// the memset of the publish words, and the host waits once, for the error word and the total.
 // Slots: 2 x grid x 16.6 KB (x 2 for two channels) = 68-136 MB instead of one per frame; no K4, no K5, no size
 // read-back before the blob is written.  The bytes are those of the slot sequence (tests pin one to the other).
 #pragma once
@@ -32,9 +35,27 @@ namespace fa {
 constexpr int kPlacedGrid = 2048;
 constexpr int kPlacedGroup = 16;  // 256-byte blocks the placement copy keeps in flight (the frame body's registers are free by then)
 
+// byte i (< 46) of a stream's fixed header: "fLaC", STREAMINFO (RFC 9639 8.2: block size B twice, frame sizes unknown,
+// 44100 Hz, nch channels of 32 bits, stream_size samples, no MD5), and the SEEKTABLE block header of nf 18-byte points --
+// the bytes write_headers_kernel / fused_finish_kernel write
+__device__ __forceinline__ uint8_t stream_header_byte(int i, int B, int nch, int64_t stream_size, int64_t nf) {
+    const uint64_t ts = ((uint64_t)stream_size < (1ULL << 36)) ? (uint64_t)stream_size : 0;
+    const uint64_t packed = ((uint64_t)44100 << 44) | ((uint64_t)(nch - 1) << 41) | ((uint64_t)31 << 36) | ts;
+    const uint32_t stl = (uint32_t)(18 * nf);
+    if (i < 4) return (uint8_t)(0x43614C66u >> (8 * i));  // "fLaC"
+    if (i < 8) return (i == 7) ? 34 : 0;
+    const int j = i - 8;  // STREAMINFO byte
+    if (j < 4) return (uint8_t)((j & 1) ? B : (B >> 8));
+    if (j < 10) return 0;
+    if (j < 18) return (uint8_t)(packed >> (56 - 8 * (j - 10)));
+    if (j < 34) return 0;
+    const int k = i - 42;  // SEEKTABLE block header (last metadata block)
+    return (k == 0) ? 0x83 : (uint8_t)(stl >> (8 * (3 - k)));
+}
+
 #if defined(FA_UNIT_PLACED) || !defined(FA_SPLIT_UNITS)
-// p: the placement half of K3F's argument block (total_frames, nframes, n_stream, hb, blob, capacity, frame_abs,
-// ticket, size_pub, off_pub, total, err, info); p.crc_tab holds K5's tables here (kCrcTabWords entries).
+// p: the placement half of K3F's argument block (total_frames, nframes, n_stream, hb, blob, capacity, ticket, size_pub,
+// off_pub, total, err, info, starts, nbytes); p.crc_tab holds K5's tables here (kCrcTabWords entries).
 #ifndef FA_PG_ATTR
 #define FA_PG_ATTR FA_K3_WAVES_ATTR
 #endif
@@ -45,7 +66,9 @@ __global__ __launch_bounds__(64) FA_PG_ATTR void encode_placed_kernel(EncodeArgs
     const int lane = threadIdx.x;
     // two slots per workgroup: the frame packed last waits in one for its offset while the next is packed into the other
     uint8_t* const slot0 = a.slots + (size_t)blockIdx.x * 2 * (size_t)a.slot_stride;
-    uint16_t* const tab = reinterpret_cast<uint16_t*>(lds);  // K5's tables take the frame image's place once the frame is packed
+    // K5's tables take the frame image's place once the frame is packed.  (Keeping them resident behind the short image of
+    // the level 0-2 kernels -- 1152 samples end at word 1428 of 4420 -- was tried: 14.2 instead of 13.0 ms on 1024 x 2^20.)
+    uint16_t* const tab = reinterpret_cast<uint16_t*>(lds);
 #ifdef FA_STAMPS  // diagnostic build: cycles per phase of the loop, summed over the frames of every 64th workgroup (stamps[20..25])
     unsigned long long pg_[6] = {0, 0, 0, 0, 0, 0}, pt_ = fa_memtime();
     if (lane == 0 && p.stamps) {  // when did this workgroup start?  (100 MHz ticks after the first one: histogram of 2.5 ms bins in stamps[32..39])
@@ -123,7 +146,26 @@ __global__ __launch_bounds__(64) FA_PG_ATTR void encode_placed_kernel(EncodeArgs
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 compact_one_frame<kPlacedGroup>(lane, reinterpret_cast<const uint32_t*>(slot0 + (size_t)(cur ^ 1) * (size_t)a.slot_stride), n_wait,
                                                 p.blob + off, tab);
-                if (lane == 0) p.frame_abs[g_wait] = (int64_t)off;
+                // ---- the stream's index entries and header fields this frame owns (what K5a / the finish kernel of K3F
+                //      write in a launch of their own): its seek point; with the stream's first frame the 46 fixed bytes
+                //      and starts[s]; with its last frame nbytes[s] ----
+                const uint32_t s = (uint32_t)g_wait / (uint32_t)a.nframes;
+                const uint32_t f = (uint32_t)g_wait - s * (uint32_t)a.nframes;
+                // (the first frame's offset is out: the scanner passes the frames in order)
+                const unsigned long long first_abs = (f == 0) ? off : lb_load(p.off_pub + (size_t)s * (size_t)a.nframes);
+                uint8_t* const h = p.blob + (first_abs - (unsigned long long)p.hb);
+                if (lane < 18) {
+                    const uint64_t sn = (uint64_t)f * (uint64_t)a.B, fo = off - first_abs;
+                    const uint32_t bsz = (f == (uint32_t)a.nframes - 1) ? (uint32_t)a.tail_bs : (uint32_t)a.B;
+                    h[46 + 18 * (size_t)f + lane] = (lane < 8) ? (uint8_t)(sn >> (56 - 8 * lane))
+                                                  : (lane < 16) ? (uint8_t)(fo >> (56 - 8 * (lane - 8)))
+                                                                : (uint8_t)(bsz >> (8 * (17 - lane)));
+                }
+                if (f == 0) {
+                    if (lane < 46) h[lane] = stream_header_byte(lane, a.B, NCH, a.stream_size, a.nframes);
+                    if (lane == 0) p.starts[s] = (int64_t)(first_abs - (unsigned long long)p.hb);
+                }
+                if (f == (uint32_t)a.nframes - 1 && lane == 0) p.nbytes[s] = (int64_t)(off + n_wait - (first_abs - (unsigned long long)p.hb));
             }
             lds_fence();  // (the table reads are done before the next frame's image overwrites them)
             FA_PG_STAMP(4);  // placement

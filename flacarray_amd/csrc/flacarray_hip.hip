@@ -356,6 +356,7 @@ struct PlacedPlan {
 };
 
 // the persistent grid (+ the scanner's workgroup), never more than frames + scanner
+constexpr int64_t kPlacedBelowFrames = 4096;  // (see placed_preferred)
 int64_t placed_grid(int64_t F) {
     int64_t g = kPlacedGrid;
     if (const char* e = std::getenv("FLACARRAY_HIP_PLACED_GRID")) {  // diagnostic: another grid (64 .. 16384 workgroups)
@@ -1275,6 +1276,15 @@ static int fused_encode_run(const void* d_data, bool f32, const float* d_quanta,
 }
 
 
+// Small arrays of K3F's geometries take K3G too: K3F's sequence is four launches and two host waits (five more launches
+// when the streams end in a short frame), K3G's is one launch and one wait, which wins until the frames are many enough
+// for K3F's faster frame loop to pay (tools/bench_placed.py).  FLACARRAY_HIP_PLACED_BELOW overrides the frame count.
+static bool placed_preferred(int64_t n_stream, int64_t stream_size) {
+    int64_t below = kPlacedBelowFrames;
+    if (const char* e = std::getenv("FLACARRAY_HIP_PLACED_BELOW")) below = std::atoll(e);
+    return n_stream * ((stream_size + kMaxBlock - 1) / kMaxBlock) < below;
+}
+
 // the single-pass sequence of every geometry K3F does not take: zero the publish words, K3G, stream headers
 static int placed_encode_run(const int32_t* d_data, int nch, int64_t n_stream, int64_t stream_size, uint32_t level, void* d_workspace,
                              int64_t workspace_bytes, unsigned char* d_bytes, int64_t capacity_bytes, int64_t* d_starts,
@@ -1350,9 +1360,13 @@ static int placed_encode_run(const int32_t* d_data, int nch, int64_t n_stream, i
         }
     }
 #endif
+    p.starts = d_starts;
+    p.nbytes = d_nbytes;
     prof_begin(0, st);
     launch_encode_placed(st, a, p, nch, placed_grid(pl.F));
     prof_end(0, st);
+    prof_end(3, st);
+    // one wait: the error word and the total (the kernel has written the index and the stream headers itself)
     int h_err = 0;
     int64_t h_tot = 0;
     FA_HIP_TRY(hipMemcpyAsync(&h_err, p.err, 4, hipMemcpyDeviceToHost, st));
@@ -1364,12 +1378,7 @@ static int placed_encode_run(const int32_t* d_data, int nch, int64_t n_stream, i
         std::fprintf(stderr, "flacarray_hip: single-pass encode failed (flags %d: 1 = offset outside the buffer, 2 = a frame timed out waiting for its offset, 4 = the scanner timed out)\n", h_err);
         return FA_ERROR_ENCODE_PROCESS;
     }
-    launch_fused_finish(st, d_bytes, p.frame_abs, p.frame_bytes, n_stream, pl.nf, stream_size, (int32_t)a.B, (int32_t)pl.tail_bs, (int32_t)nch, pl.hb,
-                        d_starts, d_nbytes, p.total);
-    prof_end(3, st);
-    FA_HIP_TRY(hipMemcpyAsync(h_total_bytes, p.total, 8, hipMemcpyDeviceToHost, st));
-    FA_HIP_TRY(hipStreamSynchronize(st));
-    FA_HIP_TRY(hipGetLastError());
+    *h_total_bytes = h_tot;
     return FA_ERROR_NONE;
 }
 
@@ -1388,7 +1397,7 @@ int fa_encode_i32_device(const int32_t* d_data, int64_t n_stream, int64_t stream
     }
     // frames K3F does not cover (short blocks of levels 0-2, streams shorter than two frames, lengths that are not a multiple
     // of 4, unaligned rows): K3G
-    if (!fused_geometry(n_stream, stream_size, level) || (reinterpret_cast<uintptr_t>(d_data) & 15))
+    if (!fused_geometry(n_stream, stream_size, level) || (reinterpret_cast<uintptr_t>(d_data) & 15) || placed_preferred(n_stream, stream_size))
         return placed_encode_run(d_data, 1, n_stream, stream_size, level, d_workspace, workspace_bytes, d_bytes, capacity_bytes, d_starts,
                                  d_nbytes, h_total_bytes, d_info, stream);
     return fused_encode_run(d_data, false, nullptr, nullptr, nullptr, n_stream, stream_size, level, d_workspace, workspace_bytes, d_bytes,

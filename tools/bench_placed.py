@@ -36,6 +36,11 @@ cases = [
     ("int32 (12, 1000) level 5  [tests/bindings.py shape]", big[:12, :1000].contiguous(), 5, 50),
     ("int32 (1, 10000) level 5  [cookbook stream]", big[:1, :10000].contiguous(), 5, 50),
     ("int32 (1000, 10000) level 5", big[:1000, :10000].contiguous(), 5, 20),
+    ("int32 (4, 8192) level 5  [whole frames]", big[:4, :8192].contiguous(), 5, 50),
+    ("int32 (64, 65536) level 5  [whole frames, 1024 of them]", big[:64, :65536].contiguous(), 5, 20),
+    ("int32 (256, 65536) level 5  [whole frames, 4096 of them]", big[:256, :65536].contiguous(), 5, 20),
+    ("int32 (1024, 65536) level 5  [whole frames, 16384 of them]", big[:1024, :65536].contiguous(), 5, 20),
+    ("int32 (1024, 65532) level 5  [16 frames + tail per stream]", big[:1024, :65532].contiguous(), 5, 20),
     ("int32 (1024, 2^20) level 1  [1152-sample blocks]", big, 1, 5),
     ("int32 (1024, 2^20 - 3) level 5  [odd length]", big[:, : (1 << 20) - 3].contiguous(), 5, 5),
     ("int64 (12, 1000) level 5", (big[:12, :1000].to(torch.int64) << 13).contiguous(), 5, 50),
