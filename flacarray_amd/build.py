@@ -36,6 +36,11 @@ MAIN_UNIT_FLAGS = [
 ]
 
 
+# The placing encoder K3G shares K3's frame body but not its flags: default scheduling strategy, and its own register
+# bounds (encode_placed.hpp, FA_PG_ATTR).
+PLACED_UNIT_FLAGS = ["-DFA_SPLIT_UNITS"]
+
+
 def needs_build():
     if not os.path.exists(OUT):
         return True
@@ -51,8 +56,8 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cflags = [f for f in FLAGS if f != "-shared"]
     objs, procs = [], []
-    # (the units compile side by side; the placing encoder shares K3's frame body and is compiled like it)
-    for src, extra in ((SRC, MAIN_UNIT_FLAGS), (SRC_COMPACT, []), (SRC_FUSED, []), (SRC_PLACED, MAIN_UNIT_FLAGS)):
+    # (the units compile side by side)
+    for src, extra in ((SRC, MAIN_UNIT_FLAGS), (SRC_COMPACT, []), (SRC_FUSED, []), (SRC_PLACED, PLACED_UNIT_FLAGS)):
         obj = os.path.join(os.path.dirname(OUT), os.path.basename(src).replace(".hip", ".o"))
         cmd = [hipcc] + cflags + extra + ["-c", "-o", obj, src]
         if verbose:

@@ -33,6 +33,9 @@ namespace fa {
 // the chip.  A grid larger than what is resident is harmless: a workgroup draws its first ticket when it starts, so the
 // ones that wait for a free CU hold no frame anybody could be waiting for.
 constexpr int kPlacedGrid = 2048;
+#ifndef FA_PG_GROUP
+#define FA_PG_GROUP kPlacedGroup
+#endif
 constexpr int kPlacedGroup = 16;  // 256-byte blocks the placement copy keeps in flight (the frame body's registers are free by then)
 
 // byte i (< 46) of a stream's fixed header: "fLaC", STREAMINFO (RFC 9639 8.2: block size B twice, frame sizes unknown,
@@ -56,8 +59,12 @@ __device__ __forceinline__ uint8_t stream_header_byte(int i, int B, int nch, int
 #if defined(FA_UNIT_PLACED) || !defined(FA_SPLIT_UNITS)
 // p: the placement half of K3F's argument block (total_frames, nframes, n_stream, hb, blob, capacity, ticket, size_pub,
 // off_pub, total, err, info, starts, nbytes); p.crc_tab holds K5's tables here (kCrcTabWords entries).
+// Register budget: the two-channel kernels need the two-waves-per-SIMD bound spelled out (left alone they take more than
+// 256 registers: one wave per SIMD, 23 instead of 16 ms on 1024 x 2^20 int64); the one-channel kernels stay at ~182 on
+// their own and run 5 % faster without it (8.45 against 8.85 ms on 1024 x (2^20 - 3) int32) -- except the fixed-predictor
+// kernels of levels 0-2, which like the bound (13.2 against 13.7 ms on 1024 x 2^20 at level 1).
 #ifndef FA_PG_ATTR
-#define FA_PG_ATTR FA_K3_WAVES_ATTR
+#define FA_PG_ATTR __attribute__((amdgpu_waves_per_eu((NCH == 2 || MLO == 0) ? 2 : 1, (NCH == 2 || MLO == 0) ? 2 : 8)))
 #endif
 template <int MLO, int NCH>
 __global__ __launch_bounds__(64) FA_PG_ATTR void encode_placed_kernel(EncodeArgs a, FusedArgs p) {
@@ -118,12 +125,17 @@ __global__ __launch_bounds__(64) FA_PG_ATTR void encode_placed_kernel(EncodeArgs
         if (have && lane == 0) t = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the next trip's)
         if (g_wait >= 0) {
             // ---- place the frame packed one trip ago: its offset has had a whole frame body's time to arrive ----
+            const uint32_t s = (uint32_t)g_wait / (uint32_t)a.nframes;
+            const uint32_t f = (uint32_t)g_wait - s * (uint32_t)a.nframes;
+            // the two offsets this step needs -- the frame's and that of its stream's first frame -- are asked for before the
+            // tables are fetched: one round trip to memory for all three instead of three in a row
+            unsigned long long off = lb_load(p.off_pub + g_wait);
+            unsigned long long first_abs = lb_load(p.off_pub + (size_t)s * (size_t)a.nframes);
             lds_fence();  // (the writer's last LDS reads are done: the image may go)
             for (int i = lane; i < kCrcTabWords / 2; i += 64) reinterpret_cast<uint32_t*>(tab)[i] = reinterpret_cast<const uint32_t*>(p.crc_tab)[i];
             FA_PG_STAMP(2);  // tables
-            unsigned long long off = 0;
             for (uint32_t spins = 0;; ++spins) {
-                off = lb_load(p.off_pub + g_wait);
+                if (spins) off = lb_load(p.off_pub + g_wait);
                 off = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
                 if (off) break;
@@ -144,15 +156,21 @@ __global__ __launch_bounds__(64) FA_PG_ATTR void encode_placed_kernel(EncodeArgs
                 // here would write back and invalidate the whole XCD's L2 once per frame and wave (measured: 2x the run time).
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                compact_one_frame<kPlacedGroup>(lane, reinterpret_cast<const uint32_t*>(slot0 + (size_t)(cur ^ 1) * (size_t)a.slot_stride), n_wait,
+                compact_one_frame<FA_PG_GROUP>(lane, reinterpret_cast<const uint32_t*>(slot0 + (size_t)(cur ^ 1) * (size_t)a.slot_stride), n_wait,
                                                 p.blob + off, tab);
                 // ---- the stream's index entries and header fields this frame owns (what K5a / the finish kernel of K3F
                 //      write in a launch of their own): its seek point; with the stream's first frame the 46 fixed bytes
                 //      and starts[s]; with its last frame nbytes[s] ----
-                const uint32_t s = (uint32_t)g_wait / (uint32_t)a.nframes;
-                const uint32_t f = (uint32_t)g_wait - s * (uint32_t)a.nframes;
-                // (the first frame's offset is out: the scanner passes the frames in order)
-                const unsigned long long first_abs = (f == 0) ? off : lb_load(p.off_pub + (size_t)s * (size_t)a.nframes);
+                // (the first frame's offset is out, or about to be: the scanner passes the frames in order, but two of its
+                // stores may land in either order)
+                if (f == 0) first_abs = off;
+                for (uint32_t spins = 0; first_abs == 0 && spins < kLbSpinLimit; ++spins) first_abs = lb_load(p.off_pub + (size_t)s * (size_t)a.nframes);
+                first_abs = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(first_abs >> 32)) << 32) |
+                            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)first_abs);
+                if (first_abs == 0) {
+                    if (lane == 0) atomicOr(p.err, 2);
+                    return;
+                }
                 uint8_t* const h = p.blob + (first_abs - (unsigned long long)p.hb);
                 if (lane < 18) {
                     const uint64_t sn = (uint64_t)f * (uint64_t)a.B, fo = off - first_abs;

@@ -389,7 +389,7 @@ int make_placed_plan(int64_t n_stream, int64_t stream_size, uint32_t level, int 
     pl->zero_bytes = o - pl->off_zero;
     pl->off_total = o;  o = align_up(o + 8, 256);
     // two slots per workgroup of the persistent grid + the placement copy's reads past the last slot's end
-    pl->off_slots = o;  o = align_up(o + (size_t)placed_grid(pl->F) * 2 * (size_t)pl->slot_stride + 256 * (size_t)kPlacedGroup + 256, 256);
+    pl->off_slots = o;  o = align_up(o + (size_t)placed_grid(pl->F) * 2 * (size_t)pl->slot_stride + 256 * (size_t)(FA_PG_GROUP) + 256, 256);
     pl->total = o;
     pl->capacity = pl->F * pl->slot_stride + n_stream * pl->hb;
     return FA_ERROR_NONE;
