@@ -346,6 +346,50 @@ def bench_cookbook(fa):
     }
 
 
+def bench_other_geometries(torch, fa, dev, level=5):
+    """Device-resident encode of the geometries the headline's kernel (K3F: full 4096-sample mono frames) does not take --
+    the reference's own test shapes (src/flacarray/tests/bindings.py:165-230), 1152-sample blocks, int64 -- through the
+    placing encoder K3G (csrc/encode_placed.hpp), each beside the slot sequence it retired (FLACARRAY_HIP_SLOTS=1, read
+    per call).  Median wall time of a call incl. its one host wait."""
+    from flacarray_amd.libflacarray import EncodeWorkspace
+
+    ws = EncodeWorkspace()
+    big = make_data(torch, 512, 1 << 20, level, dev)
+
+    def timed(x, lvl, reps):
+        ts = []
+        for i in range(reps + 1):
+            t0 = time.perf_counter()
+            out = fa.encode_flac_device(x, level=lvl, workspace=ws)
+            torch.cuda.synchronize()
+            if i:
+                ts.append(time.perf_counter() - t0)
+            del out
+        return float(np.median(ts))
+
+    res = {}
+    cases = [
+        ("int32 (12, 1000)", big[:12, :1000].contiguous(), level, 30),
+        ("int32 (1, 10000)", big[:1, :10000].contiguous(), level, 30),
+        ("int64 (12, 1000)", (big[:12, :1000].to(torch.int64) << 13).contiguous(), level, 30),
+        ("int32 (512, 2^20 - 3)", big[:, : (1 << 20) - 3].contiguous(), level, 3),
+        ("int32 (512, 2^20) level 1", big, 1, 3),
+        ("int64 (512, 2^20)", big.to(torch.int64) * 8192 + torch.randint(-4096, 4096, big.shape, device=dev, dtype=torch.int64), level, 3),
+    ]
+    for name, x, lvl, reps in cases:
+        t_new = timed(x, lvl, reps)
+        os.environ["FLACARRAY_HIP_SLOTS"] = "1"
+        try:
+            t_old = timed(x, lvl, reps)
+        finally:
+            del os.environ["FLACARRAY_HIP_SLOTS"]
+        res[name] = {"single_pass_ms": round(t_new * 1e3, 3), "slot_sequence_ms": round(t_old * 1e3, 3),
+                     "Msamples_per_s": round(x.numel() / t_new / 1e6, 1)}
+        del x
+    res["what"] = "encode_flac_device of geometries outside the headline kernel's (K3G), median ms per call; slot sequence = K3 + K4 + K5 forced"
+    return res
+
+
 def bench_cfg5(torch, fa, comp, st, nb, n_ch, n_samp, x, dev, n_req=10000, reps=5):
     """Configuration 5 on this rank's store: 10 000 scattered (channel, range) slices in one batched launch,
     from tensors resident in HBM."""
@@ -699,6 +743,12 @@ def main():
             out["cookbook"] = bench_cookbook(fa)
         except Exception as e:  # (never takes the line down)
             out["cookbook"] = f"{type(e).__name__}: {e}"[:200]
+        try:
+            torch.cuda.empty_cache()
+            L.fa_release_scratch()
+            out["other_geometries"] = bench_other_geometries(torch, fa, dev, args.level)
+        except Exception as e:  # (never takes the line down)
+            out["other_geometries"] = f"{type(e).__name__}: {e}"[:200]
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(n_samp)

@@ -23,6 +23,26 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in _lib.lib().fa_version()
 
 
+def test_single_pass_queries_cover_every_geometry():
+    """The capacity / workspace / "is there a single-pass encoder" queries are pure arithmetic (no device): every valid
+    geometry has one since round 4 -- the reference's own test shapes (tests/bindings.py:165-230), levels 0-2, int64 --
+    the worst-case capacity is one 16 640-byte slot per frame and channel + the stream headers, and the workspace of the
+    geometries K3G serves holds a few thousand slots, not one per frame."""
+    L = _lib.lib()
+    for n_stream, size, level in ((12, 1000, 5), (1, 10000, 5), (12, 1000, 0), (3, 1152 * 5 + 1, 2), (1000, 100000, 5), (4096, 1 << 20, 5)):
+        assert L.fa_encode_single_pass_supported(n_stream, size, level) == 1
+        block = 1152 if level <= 2 else 4096
+        nf = -(-size // block)
+        hb = 46 + 18 * nf
+        assert L.fa_encode_capacity_bytes(n_stream, size, level) == n_stream * (nf * 16640 + hb)
+        assert L.fa_encode_capacity_bytes_i64(n_stream, size, level) == n_stream * (nf * 2 * 16640 + hb)
+        for ws in (L.fa_encode_single_pass_workspace_bytes(n_stream, size, level), L.fa_encode_single_pass_workspace_bytes_i64(n_stream, size, level)):
+            assert 0 < ws <= 28 * n_stream * nf + 2 * 2049 * 2 * 16640 + 65536
+    assert L.fa_encode_single_pass_workspace_bytes_i64(1024, 1 << 20, 5) < 150e6 < L.fa_encode_workspace_bytes_i64(1024, 1 << 20, 5)
+    assert L.fa_encode_single_pass_supported(12, 1000, 9) == 0 and L.fa_encode_single_pass_supported(0, 1000, 5) == 0
+    assert L.fa_encode_capacity_bytes(12, 1000, 9) == -1
+
+
 def test_reference_named_header_compiles_without_libflac(tmp_path):
     """include/flacarray.h is what `cdef extern from "flacarray.h"` (libflacarray.pyx:18) finds when the binding
     is built against this library: the ten prototypes the binding declares (libflacarray.pyx:19-110) and the
