@@ -578,8 +578,14 @@ constexpr int k3_lds_words() { return kLdsWords + ((NCH == 2) ? 256 : 0); }  // 
 // calling wavefront; `lds` is the wave's frame image (k3_lds_words<NCH>() words), `lane` the lane number.  Returns the frame's bytes (the
 // CRC-16 field, the last two of them, is left zero: K5 / the placement step fills it in).  Callers: the slot kernel
 // below (one frame per workgroup) and the placing kernel of encode_placed.hpp (a ticket loop).
-template <int MLO, int NCH>
-__device__ __forceinline__ uint32_t encode_frame_body(const EncodeArgs& a, const int64_t g, uint8_t* const slot, int32_t* const lds, const int lane) {
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+// after_staging: called once per frame when the samples of the (first) subframe are in LDS and every load of the staging
+// phase has come back -- the placing encoder draws its next ticket there, in front of 10-20 us of LDS and register work.
+template <int MLO, int NCH, class Hook = NoHook>
+__device__ __forceinline__ uint32_t encode_frame_body(const EncodeArgs& a, const int64_t g, uint8_t* const slot, int32_t* const lds, const int lane,
+                                                      Hook&& after_staging = NoHook()) {
     int32_t* smp = lds;
     uint32_t* ring = reinterpret_cast<uint32_t*>(lds + kSmpWords);
     uint64_t* psum = reinterpret_cast<uint64_t*>(lds + kSmpWords + kRingWords + 2);
@@ -729,6 +735,7 @@ __device__ __forceinline__ uint32_t encode_frame_body(const EncodeArgs& a, const
     }
 
     FA_STAMP(0);
+    if (pass == first_pass) after_staging();
     const uint64_t verbatim_bits = 8 + (uint64_t)wasted + (uint64_t)bs * (uint64_t)bps;
     int type = 1;  // 0 const, 1 verbatim, 2 fixed, 3 lpc
     int order = 0, porder = 0, shift = 0, precision = 0;

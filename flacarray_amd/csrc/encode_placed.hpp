@@ -96,8 +96,11 @@ __global__ __launch_bounds__(64) FA_PG_ATTR void encode_placed_kernel(EncodeArgs
     int cur = 0;
     // One ticket = one frame.  (Four consecutive frames per ticket -- a quarter of the atomics on the one counter -- ran
     // 400 x slower: a wave waits for an offset between two frames of its ticket, so publishing frame 4k+3 came to depend
-    // on frame 4k-1 being published, a serial chain through every ticket.)  The next ticket is drawn BEFORE the placement
-    // step and looked at after it, so the counter's latency (microseconds: every wave of the chip draws from it) is hidden.
+    // on frame 4k-1 being published, a serial chain through every ticket.)  The next ticket is drawn inside the frame body
+    // (below) and looked at after the placement step, so the counter's latency is hidden.
+    // (the kernels of levels 0-2 only: 13.2 -> 12.3 ms on 1024 x 2^20 at level 1, where a frame body is 20 us and the draw's
+    // latency a quarter of it; 4096-sample frames lose 2-3 % by it, 8.47 -> 8.63-8.72 ms on 1024 x (2^20 - 3))
+    const bool early_draw = (MLO == 0) && p.total_frames > 2 * (int64_t)kPlacedGrid;
     uint32_t t = 0;
     if (lane == 0) t = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
@@ -116,13 +119,21 @@ __global__ __launch_bounds__(64) FA_PG_ATTR void encode_placed_kernel(EncodeArgs
             // lives in registers across the whole body -- 257 instead of 169 registers, i.e. one wave per SIMD instead of two)
             const int lane_f = lane_id_opaque();
             __builtin_assume(lane_f >= 0 && lane_f < 64);
-            n = encode_frame_body<MLO, NCH>(a, g, slot0 + (size_t)cur * (size_t)a.slot_stride, lds, lane_f);
+            // The next trip's ticket is drawn in the middle of the frame body, right after the staging loads: vector memory
+            // operations return in order, so drawn anywhere near other loads (the tables, the slot) its microseconds on the
+            // one counter every wave of the chip draws from stall whoever waits next; behind it here lie the fixed-predictor
+            // passes, LDS and registers only.
+            // (Arrays of a frame or two per wave draw it after the body instead: their waves run in step, a second burst of
+            // draws in the middle of the body stalls every one of them: 0.141 against 0.113 ms at 1024 frames.)
+            n = encode_frame_body<MLO, NCH>(a, g, slot0 + (size_t)cur * (size_t)a.slot_stride, lds, lane_f, [&]() __attribute__((always_inline)) {
+                if (early_draw && lane == 0) t = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            });
             // a frame is published as soon as it is packed, before this wave waits for anything: whoever holds a ticket
             // publishes without depending on anybody, so every wait below ends
             if (lane == 0) __hip_atomic_store(p.size_pub + g, 0x80000000u | n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         FA_PG_STAMP(1);  // frame body
-        if (have && lane == 0) t = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the next trip's)
+        if (!early_draw && have && lane == 0) t = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (g_wait >= 0) {
             // ---- place the frame packed one trip ago: its offset has had a whole frame body's time to arrive ----
             const uint32_t s = (uint32_t)g_wait / (uint32_t)a.nframes;
