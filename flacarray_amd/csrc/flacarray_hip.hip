@@ -385,7 +385,7 @@ int make_placed_plan(int64_t n_stream, int64_t stream_size, uint32_t level, int 
     pl->off_zero = o;   // everything from here to off_total is zeroed before every launch
     pl->off_size = o;   o = align_up(o + (size_t)pl->F * 4, 256);
     pl->off_off = o;    o = align_up(o + (size_t)pl->F * 8, 256);
-    pl->off_ticket = o; o = align_up(o + 16, 256);  // ticket word, error flags
+    pl->off_ticket = o; o = align_up(o + 32, 256);  // ticket word, error flags, the scanner's total
     pl->zero_bytes = o - pl->off_zero;
     pl->off_total = o;  o = align_up(o + 8, 256);
     // two slots per workgroup of the persistent grid + the placement copy's reads past the last slot's end
@@ -1187,7 +1187,7 @@ static int fused_encode_run(const void* d_data, bool f32, const float* d_quanta,
     a.info = reinterpret_cast<FrameInfo*>(d_info);
     a.size_pub = reinterpret_cast<uint32_t*>(ws + pl.off_size);
     a.off_pub = reinterpret_cast<unsigned long long*>(ws + pl.off_off);
-    a.total = reinterpret_cast<int64_t*>(ws + pl.off_total);
+    a.total = reinterpret_cast<int64_t*>(ws + pl.off_ticket + 16);  // (next to the error and NaN words: one copy brings all three back)
     a.ticket = reinterpret_cast<uint32_t*>(ws + pl.off_ticket);
     a.err = reinterpret_cast<int*>(ws + pl.off_ticket + 8);
 #ifdef FA_STAMPS
@@ -1228,20 +1228,18 @@ static int fused_encode_run(const void* d_data, bool f32, const float* d_quanta,
     prof_begin(0, st);
     launch_fused_encode(st, a, f32);
     prof_end(0, st);
-    int64_t* d_total = reinterpret_cast<int64_t*>(ws + pl.off_total);
-    int h_err = 0;
+    struct { int32_t err, nan; int64_t total; } back = {0, 0, 0};
+    static_assert(sizeof back == 16, "error word at +8, NaN flag at +12, total at +16 of the ticket block");
     {
         // A frame that was dropped (no offset in time, or an offset outside the buffer) leaves frame_abs / off_pub of
         // itself -- and, after a scanner time-out, of every frame behind it -- unwritten: the kernels below would
         // turn those into addresses.  They run only after the error word has come back clean (one stream
-        // synchronisation, ~20 us against a 15 ms kernel).
-        int64_t h_tot = 0;
-        FA_HIP_TRY(hipMemcpyAsync(&h_err, a.err, 4, hipMemcpyDeviceToHost, st));
-        FA_HIP_TRY(hipMemcpyAsync(&h_tot, d_total, 8, hipMemcpyDeviceToHost, st));  // (the scanner's total: headers and tails included)
+        // synchronisation, ~20 us against a 15 ms kernel).  Nothing behind this point changes the three words.
+        FA_HIP_TRY(hipMemcpyAsync(&back, a.err, sizeof back, hipMemcpyDeviceToHost, st));  // (the scanner's total: headers and tails included)
         FA_HIP_TRY(hipStreamSynchronize(st));
-        if (h_err == 1 || (h_err == 0 && h_tot > capacity_bytes)) return FA_ERROR_ALLOC;  // the blob does not fit the caller's buffer: nothing else is launched
-        if (h_err) {
-            std::fprintf(stderr, "flacarray_hip: single-pass encode failed (flags %d: 1 = offset outside the buffer, 2 = a frame timed out waiting for its offset, 4 = the scanner timed out)\n", h_err);
+        if (back.err == 1 || (back.err == 0 && back.total > capacity_bytes)) return FA_ERROR_ALLOC;  // the blob does not fit the caller's buffer: nothing else is launched
+        if (back.err) {
+            std::fprintf(stderr, "flacarray_hip: single-pass encode failed (flags %d: 1 = offset outside the buffer, 2 = a frame timed out waiting for its offset, 4 = the scanner timed out)\n", back.err);
             return FA_ERROR_ENCODE_PROCESS;
         }
     }
@@ -1259,19 +1257,12 @@ static int fused_encode_run(const void* d_data, bool f32, const float* d_quanta,
         launch_compact_frames(st, nblk, reinterpret_cast<const uint8_t*>(ws + pl.off_tslots), tb, toff, tzero, 1, n_stream, crc5, d_bytes, kSlotBytes);
     }
     launch_fused_finish(st, d_bytes, a.frame_abs, a.frame_bytes, n_stream, pl.nf, stream_size, (int32_t)kMaxBlock, (int32_t)pl.tail_bs, 1, pl.hb,
-                        d_starts, d_nbytes, d_total);
+                        d_starts, d_nbytes, a.total);
     prof_end(3, st);
-    int h_nan = 0;
-    FA_HIP_TRY(hipMemcpyAsync(&h_err, a.err, 4, hipMemcpyDeviceToHost, st));
-    FA_HIP_TRY(hipMemcpyAsync(&h_nan, d_nanflag, 4, hipMemcpyDeviceToHost, st));
-    FA_HIP_TRY(hipMemcpyAsync(h_total_bytes, d_total, 8, hipMemcpyDeviceToHost, st));
     FA_HIP_TRY(hipStreamSynchronize(st));
     FA_HIP_TRY(hipGetLastError());
-    if (h_nan & 1) return FA_ERROR_NAN_INPUT;
-    if (h_err) {
-        std::fprintf(stderr, "flacarray_hip: single-pass encode failed (flags %d: 1 = offset outside the buffer, 2 = a frame timed out waiting for its offset, 4 = the scanner timed out)\n", h_err);
-        return FA_ERROR_ENCODE_PROCESS;
-    }
+    *h_total_bytes = back.total;
+    if (back.nan & 1) return FA_ERROR_NAN_INPUT;
     return FA_ERROR_NONE;
 }
 
@@ -1344,7 +1335,8 @@ static int placed_encode_run(const int32_t* d_data, int nch, int64_t n_stream, i
     p.info = a.info;
     p.size_pub = reinterpret_cast<uint32_t*>(ws + pl.off_size);
     p.off_pub = reinterpret_cast<unsigned long long*>(ws + pl.off_off);
-    p.total = reinterpret_cast<int64_t*>(ws + pl.off_total);
+    // (the scanner's total lands next to the error word, inside the 256 zeroed bytes that hold the ticket: one copy brings both back)
+    p.total = reinterpret_cast<int64_t*>(ws + pl.off_ticket + 16);
     p.ticket = reinterpret_cast<uint32_t*>(ws + pl.off_ticket);
     p.err = reinterpret_cast<int*>(ws + pl.off_ticket + 8);
     rc = get_crc_tab(&p.crc_tab);  // (K5's tables: the placement step is K5's per-frame copy)
@@ -1367,12 +1359,13 @@ static int placed_encode_run(const int32_t* d_data, int nch, int64_t n_stream, i
     prof_end(0, st);
     prof_end(3, st);
     // one wait: the error word and the total (the kernel has written the index and the stream headers itself)
-    int h_err = 0;
-    int64_t h_tot = 0;
-    FA_HIP_TRY(hipMemcpyAsync(&h_err, p.err, 4, hipMemcpyDeviceToHost, st));
-    FA_HIP_TRY(hipMemcpyAsync(&h_tot, p.total, 8, hipMemcpyDeviceToHost, st));
+    struct { int32_t err, pad; int64_t total; } back = {0, 0, 0};
+    static_assert(sizeof back == 16, "error word at +8, total at +16 of the ticket block");
+    FA_HIP_TRY(hipMemcpyAsync(&back, p.err, sizeof back, hipMemcpyDeviceToHost, st));
     FA_HIP_TRY(hipStreamSynchronize(st));
     FA_HIP_TRY(hipGetLastError());
+    const int h_err = back.err;
+    const int64_t h_tot = back.total;
     if (h_err == 1 || (h_err == 0 && h_tot > capacity_bytes)) return FA_ERROR_ALLOC;  // the blob does not fit the caller's buffer
     if (h_err) {
         std::fprintf(stderr, "flacarray_hip: single-pass encode failed (flags %d: 1 = offset outside the buffer, 2 = a frame timed out waiting for its offset, 4 = the scanner timed out)\n", h_err);
