@@ -73,9 +73,19 @@ __global__ __launch_bounds__(64) FA_PG_ATTR void encode_placed_kernel(EncodeArgs
     const int lane = threadIdx.x;
     // two slots per workgroup: the frame packed last waits in one for its offset while the next is packed into the other
     uint8_t* const slot0 = a.slots + (size_t)blockIdx.x * 2 * (size_t)a.slot_stride;
-    // K5's tables take the frame image's place once the frame is packed.  (Keeping them resident behind the short image of
-    // the level 0-2 kernels -- 1152 samples end at word 1428 of 4420 -- was tried: 14.2 instead of 13.0 ms on 1024 x 2^20.)
-    uint16_t* const tab = reinterpret_cast<uint16_t*>(lds);
+    // K5's tables take the frame image's place once the frame is packed -- except in the kernels of levels 0-2, whose
+    // 1152-sample image (staged in 5 rows of 256: 21 chunks of 68 words) ends at word 1428 of the 4420: there the tables
+    // sit behind it for the whole launch (12.45 -> 11.92 ms on 1024 x 2^20 at level 1, A/B in one call; the same change
+    // measured while the loop still waited for offsets in line looked like a loss).
+#ifndef FA_PG_TABRES
+#define FA_PG_TABRES 1
+#endif
+    constexpr bool kTabResident = FA_PG_TABRES && (MLO == 0);
+    static_assert(!kTabResident || (1536 + kCrcTabWords / 2 <= kSmpWords && 1536 >= ((1152 + kRow - 1) / kRow * kRow / kChunk + 1) * kChunkStride), "the resident tables lie behind the short image");
+    uint16_t* const tab = reinterpret_cast<uint16_t*>(lds + (kTabResident ? 1536 : 0));
+    if (kTabResident) {
+        for (int i = lane; i < kCrcTabWords / 2; i += 64) reinterpret_cast<uint32_t*>(tab)[i] = reinterpret_cast<const uint32_t*>(p.crc_tab)[i];
+    }
 #ifdef FA_STAMPS  // diagnostic build: cycles per phase of the loop, summed over the frames of every 64th workgroup (stamps[20..25])
     unsigned long long pg_[6] = {0, 0, 0, 0, 0, 0}, pt_ = fa_memtime();
     if (lane == 0 && p.stamps) {  // when did this workgroup start?  (100 MHz ticks after the first one: histogram of 2.5 ms bins in stamps[32..39])
@@ -143,7 +153,9 @@ __global__ __launch_bounds__(64) FA_PG_ATTR void encode_placed_kernel(EncodeArgs
             unsigned long long off = lb_load(p.off_pub + g_wait);
             unsigned long long first_abs = lb_load(p.off_pub + (size_t)s * (size_t)a.nframes);
             lds_fence();  // (the writer's last LDS reads are done: the image may go)
-            for (int i = lane; i < kCrcTabWords / 2; i += 64) reinterpret_cast<uint32_t*>(tab)[i] = reinterpret_cast<const uint32_t*>(p.crc_tab)[i];
+            if (!kTabResident) {
+                for (int i = lane; i < kCrcTabWords / 2; i += 64) reinterpret_cast<uint32_t*>(tab)[i] = reinterpret_cast<const uint32_t*>(p.crc_tab)[i];
+            }
             FA_PG_STAMP(2);  // tables
             for (uint32_t spins = 0;; ++spins) {
                 if (spins) off = lb_load(p.off_pub + g_wait);
