@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64) FA_PG_ATTR void encode_placed_kernel(EncodeArgs
         for (int i = lane; i < kCrcTabWords / 2; i += 64) reinterpret_cast<uint32_t*>(tab)[i] = reinterpret_cast<const uint32_t*>(p.crc_tab)[i];
     }
 #ifdef FA_STAMPS  // diagnostic build: cycles per phase of the loop, summed over the frames of every 64th workgroup (stamps[20..25])
-    unsigned long long pg_[6] = {0, 0, 0, 0, 0, 0}, pt_ = fa_memtime();
+    unsigned long long pg_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_ = fa_memtime();
     if (lane == 0 && p.stamps) {  // when did this workgroup start?  (100 MHz ticks after the first one: histogram of 2.5 ms bins in stamps[32..39])
         const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();
         const unsigned long long old_ = atomicCAS(&p.stamps[28], 0ULL, now_);
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64) FA_PG_ATTR void encode_placed_kernel(EncodeArgs
         atomicAdd(&p.stamps[32 + (b_ > 7 ? 7 : b_)], 1ULL);
     }
 #define FA_PG_STAMP(k) do { const unsigned long long n_ = fa_memtime(); pg_[k] += n_ - pt_; pt_ = n_; } while (0)
-#define FA_PG_FLUSH do { if (lane == 0 && p.stamps) { if ((blockIdx.x & 63) == 1) for (int i_ = 0; i_ < 6; ++i_) atomicAdd(&p.stamps[20 + i_], pg_[i_]); if (pg_[5]) atomicAdd(&p.stamps[26], 1ULL); atomicMax(&p.stamps[27], pg_[5]); } } while (0)
+#define FA_PG_FLUSH do { if (lane == 0 && p.stamps) { if ((blockIdx.x & 63) == 1) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&p.stamps[20 + i_], pg_[i_]); if (pg_[5]) atomicAdd(&p.stamps[30], 1ULL); atomicMax(&p.stamps[31], pg_[5]); } } while (0)
 #else
 #define FA_PG_STAMP(k) do { } while (0)
 #define FA_PG_FLUSH do { } while (0)
@@ -181,6 +181,7 @@ __global__ __launch_bounds__(64) FA_PG_ATTR void encode_placed_kernel(EncodeArgs
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 compact_one_frame<FA_PG_GROUP>(lane, reinterpret_cast<const uint32_t*>(slot0 + (size_t)(cur ^ 1) * (size_t)a.slot_stride), n_wait,
                                                 p.blob + off, tab);
+                FA_PG_STAMP(4);  // placement: the copy
                 // ---- the stream's index entries and header fields this frame owns (what K5a / the finish kernel of K3F
                 //      write in a launch of their own): its seek point; with the stream's first frame the 46 fixed bytes
                 //      and starts[s]; with its last frame nbytes[s] ----
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(64) FA_PG_ATTR void encode_placed_kernel(EncodeArgs
                 if (f == (uint32_t)a.nframes - 1 && lane == 0) p.nbytes[s] = (int64_t)(off + n_wait - (first_abs - (unsigned long long)p.hb));
             }
             lds_fence();  // (the table reads are done before the next frame's image overwrites them)
-            FA_PG_STAMP(4);  // placement
+            FA_PG_STAMP(6);  // placement: seek point, header, index
 #ifdef FA_STAMPS
             pg_[5] += 1;
 #endif

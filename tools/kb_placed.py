@@ -66,12 +66,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
             buf = (ctypes.c_ulonglong * 64)()
             L.fa_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
             L.fa_debug_stamps(buf, 1)
-            v = [buf[20 + i] for i in range(5)]
+            v = [buf[20 + i] for i in (0, 1, 2, 3, 4, 6)]
             tot = float(sum(v)) or 1.0
-            print(f"   workgroups that encoded at least one frame (6 calls): {buf[26]}, most frames in one workgroup {buf[27]}", flush=True)
+            print(f"   workgroups that encoded at least one frame (6 calls): {buf[30]}, most frames in one workgroup {buf[31]}", flush=True)
             print("   workgroup starts by 2.5 ms bin after the first one (all calls): " + " ".join(str(buf[32 + i]) for i in range(8)), flush=True)
             print(f"   frames stamped {buf[25]} (6 calls), s_memtime ticks per frame {tot / max(1, buf[25]):.0f} (100 MHz: x 0.01 us)", flush=True)
-            print("   phase shares of a wave's loop: " + ", ".join(f"{n} {100 * c / tot:.1f} %" for n, c in zip(("ticket", "frame body", "tables", "wait for offset", "placement"), v)), flush=True)
+            print("   phase shares of a wave's loop: " + ", ".join(f"{n} {100 * c / tot:.1f} %" for n, c in zip(("ticket", "frame body", "tables", "wait for offset", "placement copy", "headers + index"), v)), flush=True)
     sys.exit(0)
 for spec in sys.argv[1:]:
     env = dict(os.environ)
