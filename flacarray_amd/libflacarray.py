@@ -487,6 +487,25 @@ def _dp(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+class _NoSwitch:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def _on_device(device):
+    """`torch.cuda.device(device)` only when that is a switch: entering and leaving the context manager costs ~8 us, a
+    tenth of a small call, and nearly every call runs on the current device already."""
+    torch = _torch()
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return _NO_SWITCH if idx == torch.cuda.current_device() else torch.cuda.device(device)
+
+
 class EncodeWorkspace:
     """Reusable HBM scratch for encode_flac_device (per-frame slots + scan arrays)."""
 
@@ -535,8 +554,8 @@ def encode_flac_device(data, level=5, workspace=None, return_info=False, compact
     L = _lib.lib()
     if workspace is None:
         workspace = EncodeWorkspace()
-    starts = torch.empty(n_stream, dtype=torch.int64, device=data.device)
-    nbytes = torch.empty(n_stream, dtype=torch.int64, device=data.device)
+    index = torch.empty(2 * n_stream, dtype=torch.int64, device=data.device)  # (one allocation: starts | nbytes)
+    starts, nbytes = index[:n_stream], index[n_stream:]
     info = None
     if return_info:
         bs = 1152 if level <= 2 else 4096
@@ -548,7 +567,7 @@ def encode_flac_device(data, level=5, workspace=None, return_info=False, compact
         if capacity_bytes is not None:
             cap = min(cap, int(capacity_bytes))
         ws = workspace.get((L.fa_encode_single_pass_workspace_bytes_i64 if i64 else L.fa_encode_single_pass_workspace_bytes)(n_stream, stream_size, level), data.device)
-        with torch.cuda.device(data.device):
+        with _on_device(data.device):
             buf = torch.empty(cap, dtype=torch.uint8, device=data.device)
             errcode = (L.fa_encode_i64_device if i64 else L.fa_encode_i32_device)(
                 _dp(data), n_stream, stream_size, level, _dp(ws), ws.numel(), _dp(buf), cap, _dp(starts), _dp(nbytes),
@@ -565,7 +584,7 @@ def encode_flac_device(data, level=5, workspace=None, return_info=False, compact
     if ws_bytes < 0:
         raise RuntimeError("Encoding failed, return code = 512")
     ws = workspace.get(ws_bytes, data.device)
-    with torch.cuda.device(data.device):
+    with _on_device(data.device):
         errcode = (L.fa_encode_i64_device_begin if i64 else L.fa_encode_i32_device_begin)(
             _dp(data), n_stream, stream_size, level, _dp(ws), ws.numel(), _dp(starts), _dp(nbytes), ctypes.byref(total),
             _dp(info), _stream_ptr(),
@@ -633,7 +652,7 @@ def encode_flac_device_f32(data, quanta=None, level=5, workspace=None, compact=F
     cap = L.fa_encode_capacity_bytes(n_stream, stream_size, level)
     ws = workspace.get(L.fa_encode_single_pass_workspace_bytes(n_stream, stream_size, level), data.device)
     total = ctypes.c_int64(0)
-    with torch.cuda.device(data.device):
+    with _on_device(data.device):
         buf = torch.empty(cap, dtype=torch.uint8, device=data.device)
         errcode = L.fa_encode_f32_device(
             _dp(data), n_stream, stream_size, level, _dp(q), _dp(ws), ws.numel(), _dp(buf), cap, _dp(starts), _dp(nbytes),
@@ -705,7 +724,7 @@ def decode_flac_device(compressed, starts, nbytes, stream_size, first_sample=-1,
     dev = compressed.device
     L = _lib.lib()
     if is_int64:
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             if offsets is None:
                 out = torch.empty(shape, dtype=torch.int64, device=dev)
                 errcode = L.fa_decode_i64_device(
@@ -723,7 +742,7 @@ def decode_flac_device(compressed, starts, nbytes, stream_size, first_sample=-1,
         if errcode != 0:
             return _device_regroup(errcode, out, compressed, starts, nbytes, stream_size, first_sample, last_sample, offsets, gains, True)
         return out
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         if offsets is None:
             out = torch.empty(shape, dtype=torch.int32, device=dev)
             errcode = L.fa_decode_i32_device(
@@ -767,7 +786,7 @@ def decode_slices_device(compressed, starts, nbytes, stream_size, slice_stream, 
         # per-stream offsets / gains; the kernel looks them up by the slice's stream
         soff = offsets.reshape(-1).to(device=dev, dtype=ft).contiguous()
         sgain = gains.reshape(-1).to(device=dev, dtype=ft).contiguous()
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         errcode = (L.fa_decode_slices_i64_device if is_int64 else L.fa_decode_slices_i32_device)(
             _dp(compressed), compressed.numel(), _dp(starts), _dp(nbytes), n_stream, stream_size, n,
             ctypes.c_void_p(slice_stream.ctypes.data), ctypes.c_void_p(slice_first.ctypes.data),
@@ -798,7 +817,7 @@ class DeviceDecodeIndex:
         self.device = compressed.device
         self._L = _lib.lib()
         h = ctypes.c_void_p(None)
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             errcode = self._L.fa_decode_index_create(
                 _dp(self.compressed), self.compressed.numel(), _dp(self.starts), _dp(self.nbytes), self.n_stream, self.stream_size,
                 2 if is_int64 else 1, ctypes.byref(h), _stream_ptr(),
@@ -842,7 +861,7 @@ class DeviceDecodeIndex:
         if offsets is not None:
             offsets = offsets.reshape(-1).to(device=self.device, dtype=ft).contiguous()
             gains = gains.reshape(-1).to(device=self.device, dtype=ft).contiguous()
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             errcode = self._L.fa_decode_indexed(
                 self._h, first_sample, last_sample, -1, None, None, None, None, None if offsets is not None else _dp(out),
                 _dp(out) if offsets is not None else None, _dp(offsets), _dp(gains), _stream_ptr(), _verify_arg(verify),
@@ -876,7 +895,7 @@ class DeviceDecodeIndex:
             host = _pinned_pool.empty(out.numel(), ndt) if out.numel() * ndt.itemsize >= 65536 else None
             if host is None:
                 host = np.empty(out.numel(), dtype=ndt)
-            with torch.cuda.device(self.device):
+            with _on_device(self.device):
                 errcode = self._L.fa_decode_indexed_host(
                     self._h, n, ctypes.c_void_p(slice_stream.ctypes.data), ctypes.c_void_p(slice_first.ctypes.data),
                     ctypes.c_void_p(slice_count.ctypes.data), ctypes.c_void_p(out_off.ctypes.data),
@@ -886,7 +905,7 @@ class DeviceDecodeIndex:
             if errcode != 0:
                 raise RuntimeError(f"Decoding failed, return code = {errcode}")
             return host, out_off
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             errcode = self._L.fa_decode_indexed(
                 self._h, -1, -1, n, ctypes.c_void_p(slice_stream.ctypes.data), ctypes.c_void_p(slice_first.ctypes.data),
                 ctypes.c_void_p(slice_count.ctypes.data), ctypes.c_void_p(out_off.ctypes.data),
@@ -914,7 +933,7 @@ def float32_to_int32_device(data, quanta=None):
         q = quanta.to(device=data.device, dtype=torch.float32).reshape(-1).contiguous()
         if q.numel() != n_stream:
             raise RuntimeError("quanta must have one entry per stream")
-    with torch.cuda.device(data.device):
+    with _on_device(data.device):
         errcode = _lib.lib().fa_float32_to_int32_device(
             _dp(data), n_stream, stream_size, _dp(q), _dp(out), _dp(offsets), _dp(gains), _stream_ptr()
         )
