@@ -489,6 +489,17 @@ def test_placing_encoder_and_slot_sequence_write_the_same_bytes(fa, oracle):
         blob, st, nb = (oracle.encode_i64 if x_.dtype == np.int64 else oracle.encode_i32)(x_, level)
         assert np.array_equal(a[0].cpu().numpy(), blob) and np.array_equal(a[1].cpu().numpy(), st) and np.array_equal(a[2].cpu().numpy(), nb)
         assert torch.equal(fa.decode_flac_device(*a, x_.shape[1], is_int64=x_.dtype == np.int64).cpu(), torch.from_numpy(x_))
+    # the persistent grid is a performance choice, not a correctness one: 64 workgroups (far fewer than frames or than the
+    # chip holds) and 16 384 (most of them start when the tickets are gone, or find the chip full) write the same bytes
+    d = torch.from_numpy(many).cuda()
+    ref = fa.encode_flac_device(d, level=1)
+    for grid in ("64", "16384"):
+        os.environ["FLACARRAY_HIP_PLACED_GRID"] = grid
+        try:
+            got = fa.encode_flac_device(d, level=1)
+        finally:
+            del os.environ["FLACARRAY_HIP_PLACED_GRID"]
+        assert all(torch.equal(u, v) for u, v in zip(ref, got)), grid
     # rows that start 4 bytes off a 16-byte boundary (a view into a larger tensor): K3G instead of K3F, same bytes
     big = torch.from_numpy(np.concatenate([np.zeros(1, np.int32), sinusoid_noise_i32(3, 8192, seed=84).reshape(-1)])).cuda()
     view = big[1:].reshape(3, 8192)
