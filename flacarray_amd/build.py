@@ -48,18 +48,26 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build(force=False, verbose=False):
-    """Compile the library if it is missing or older than its sources; returns its path."""
+def build(force=False, verbose=False, extra=(), name=None):
+    """Compile the library if it is missing or older than its sources; returns its path.  `name` / `extra`: a variant
+    lib/libflacarray_hip_<name>.so of the SHIPPED structure (four units, their flags) with more -D flags -- what an A/B
+    against the shipped library needs when the kernels' co-residency depends on the units' flags (K9 beside K7)."""
+    if name:
+        return _build_units(OUT.replace(".so", f"_{name}.so"), list(extra), verbose, tag=name)
     if not force and not needs_build():
         return OUT
+    return _build_units(OUT, [], verbose)
+
+
+def _build_units(OUT, more, verbose, tag=""):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cflags = [f for f in FLAGS if f != "-shared"]
     objs, procs = [], []
     # (the units compile side by side)
     for src, extra in ((SRC, MAIN_UNIT_FLAGS), (SRC_COMPACT, []), (SRC_FUSED, []), (SRC_PLACED, PLACED_UNIT_FLAGS)):
-        obj = os.path.join(os.path.dirname(OUT), os.path.basename(src).replace(".hip", ".o"))
-        cmd = [hipcc] + cflags + extra + ["-c", "-o", obj, src]
+        obj = os.path.join(os.path.dirname(OUT), os.path.basename(src).replace(".hip", f"{tag}.o"))
+        cmd = [hipcc] + cflags + extra + more + ["-c", "-o", obj, src]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((cmd, subprocess.Popen(cmd)))
@@ -93,7 +101,10 @@ def build_variant(name, defines, verbose=False):
 
 
 if __name__ == "__main__":
-    if "--variant" in sys.argv:
+    if "--split-variant" in sys.argv:
+        i = sys.argv.index("--split-variant")
+        print(build(verbose=True, name=sys.argv[i + 1], extra=sys.argv[i + 2:]))
+    elif "--variant" in sys.argv:
         i = sys.argv.index("--variant")
         print(build_variant(sys.argv[i + 1], sys.argv[i + 2:], verbose=True))
     elif "--stamps" in sys.argv:

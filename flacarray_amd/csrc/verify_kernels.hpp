@@ -41,7 +41,10 @@ __global__ __launch_bounds__(256) void verify_crc16_kernel(DecodeArgs a, const u
     // takes 7).  A trip whose 2048 bytes lie inside the frame's CRC range and inside the blob (wave-uniform test) runs
     // without per-word masks or address arithmetic (one address, immediate offsets: the kernel must stay within 48 registers,
     // what a SIMD has left beside two waves of K7); the frame's last bytes go word by word.
-    constexpr int kBatch = 8;
+#ifndef FA_K9_BATCH
+#define FA_K9_BATCH 8
+#endif
+    constexpr int kBatch = FA_K9_BATCH;
     const uint32_t Lin = (uint32_t)(((int64_t)L < a.blob_bytes - start ? (int64_t)L : a.blob_bytes - start) & ~(int64_t)3);  // whole words inside both
     uint32_t base = 0;
     for (; base + 256u * kBatch <= Lin; base += 256u * kBatch) {
