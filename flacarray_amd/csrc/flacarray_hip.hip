@@ -1272,7 +1272,9 @@ static int fused_encode_run(const void* d_data, bool f32, const float* d_quanta,
 // when the streams end in a short frame), K3G's is one launch and one wait, which wins until the frames are many enough
 // for K3F's faster frame loop to pay (tools/bench_placed.py).  FLACARRAY_HIP_PLACED_BELOW overrides the frame count.
 static bool placed_preferred(int64_t n_stream, int64_t stream_size) {
-    int64_t below = kPlacedBelowFrames;
+    // (tools/kb_crossover_placed.py, whole frames: 512 frames 0.089 against 0.096 ms, 1024 frames 0.104 against 0.099, 2048
+    // frames 0.144 against 0.115; streams that end in a short frame add five launches to K3F's side: 3000 frames 0.166 against 0.22)
+    int64_t below = (stream_size % kMaxBlock == 0) ? kPlacedBelowFrames / 4 : kPlacedBelowFrames;
     if (const char* e = std::getenv("FLACARRAY_HIP_PLACED_BELOW")) below = std::atoll(e);
     return n_stream * ((stream_size + kMaxBlock - 1) / kMaxBlock) < below;
 }

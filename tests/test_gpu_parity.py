@@ -19,12 +19,16 @@ def fa():
 @pytest.fixture(autouse=True, params=["auto", "k7"])
 def decoder_dispatch(request, monkeypatch):
     """Launches of up to 4096 frames go to the wave-per-frame decoder K7L, larger ones to K7 (lane per frame, the
-    headline kernel).  The cases of this file are small, so left alone they would all exercise K7L: every test runs
-    twice, once with the library's own dispatch and once with K7L switched off (the variable is read per call)."""
+    headline kernel); arrays of fewer than 1024 / 4096 frames are encoded by the placing encoder K3G, larger ones of the
+    headline geometry by K3F.  The cases of this file are small, so left alone they would all exercise K7L and K3G: every
+    test runs twice, once with the library's own dispatch and once with K7L switched off and K3F taking every array of
+    its geometry (the variables are read per call)."""
     if request.param == "k7":
         monkeypatch.setenv("FLACARRAY_HIP_LATENCY", "0")
+        monkeypatch.setenv("FLACARRAY_HIP_PLACED_BELOW", "0")
     else:
         monkeypatch.delenv("FLACARRAY_HIP_LATENCY", raising=False)
+        monkeypatch.delenv("FLACARRAY_HIP_PLACED_BELOW", raising=False)
     return request.param
 
 
