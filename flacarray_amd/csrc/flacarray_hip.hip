@@ -1260,7 +1260,9 @@ static int fused_encode_run(const void* d_data, bool f32, const float* d_quanta,
     launch_fused_finish(st, d_bytes, a.frame_abs, a.frame_bytes, n_stream, pl.nf, stream_size, (int32_t)kMaxBlock, (int32_t)pl.tail_bs, 1, pl.hb,
                         d_starts, d_nbytes, a.total);
     prof_end(3, st);
-    FA_HIP_TRY(hipStreamSynchronize(st));
+    // No second wait: the error word, the NaN flag and the total are in hand, and what is still queued (a short-frame
+    // compaction, the header / index kernel: microseconds) completes in stream order like everything else a caller
+    // queues behind this call -- one host wait per encode (0.172 -> 0.157 ms at 4096 frames).
     FA_HIP_TRY(hipGetLastError());
     *h_total_bytes = back.total;
     if (back.nan & 1) return FA_ERROR_NAN_INPUT;

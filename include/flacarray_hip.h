@@ -120,7 +120,9 @@ int fa_encode_i32_device_finish(int64_t n_stream, int64_t stream_size, uint32_t 
  * that sends everything through begin + finish).  The caller provides d_bytes with fa_encode_capacity_bytes() bytes
  * (worst case: every frame VERBATIM; a smaller buffer is accepted -- if the blob does not fit, nothing outside the
  * buffer is written and the call returns FA_ERROR_ALLOC) and a workspace of fa_encode_single_pass_workspace_bytes(); the
- * encoded triple is d_bytes[0, *h_total_bytes), d_starts, d_nbytes.  Same bytes as begin + finish in every case. */
+ * encoded triple is d_bytes[0, *h_total_bytes), d_starts, d_nbytes.  Same bytes as begin + finish in every case.
+ * The call waits on `stream` once (for the error word and the total, which is valid on return); d_bytes / d_starts / d_nbytes
+ * are complete in stream order: K3F's header and index kernel may still be queued when the call returns. */
 int fa_encode_single_pass_supported(int64_t n_stream, int64_t stream_size, uint32_t level);
 int64_t fa_encode_capacity_bytes(int64_t n_stream, int64_t stream_size, uint32_t level);
 int64_t fa_encode_single_pass_workspace_bytes(int64_t n_stream, int64_t stream_size, uint32_t level);
