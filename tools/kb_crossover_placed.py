@@ -30,6 +30,15 @@ def timed(x, reps=30):
     return float(np.median(ts)) * 1e3
 
 
+tails = bench.make_data(torch, 2048, 10000, 5, dev)  # streams of 2 full frames + a short one
+for n in (256, 512, 768, 1024, 1365, 2048):
+    x = tails[:n].contiguous()
+    os.environ["FLACARRAY_HIP_PLACED_BELOW"] = "0"
+    t_f = timed(x)
+    os.environ["FLACARRAY_HIP_PLACED_BELOW"] = "1000000000"
+    t_g = timed(x)
+    del os.environ["FLACARRAY_HIP_PLACED_BELOW"]
+    print(f"{n * 3:6d} frames ({n} x 10000, short last frames): K3F + detour {t_f:.3f} ms, K3G {t_g:.3f} ms", flush=True)
 for n in (32, 64, 96, 128, 160, 192, 256, 384, 512):
     x = big[:n].contiguous()
     os.environ["FLACARRAY_HIP_PLACED_BELOW"] = "0"
